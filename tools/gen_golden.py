@@ -1,0 +1,292 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures under tests/golden/ by RUNNING the reference.
+
+Runs only in the build container (needs /root/reference). The reference's
+``qpth`` package is imported as-is (read-only tree, no bytecode written); the
+only obstacle is its top-level ``import ipdb`` (qpth/al_utils.py:3,
+qpth/AL_mpc.py:18), satisfied by tools/_stubs/ipdb.py (ours).
+
+For every case the script records
+  * the inputs (Qd, q, F, c, x0, u_lo, u_hi, z0),
+  * per Newton step: gradient g, Newton update d, the 20 line-search merit
+    values, chosen index k, accept bit, the iterate z after the step
+    (hooks on al_utils.merit_grad_hessian / al_utils.line_search_newton),
+  * for the first Newton step of each AL iteration the block-tridiagonal band of
+    the dense Hessian (and asserts everything outside the band is exactly 0),
+  * per AL iteration: number of Newton steps executed, lamda, rho,
+  * final x, u (fp32, as the reference returns them),
+  * optionally the backward pass (gradients w.r.t. q and diag(Q)).
+
+Fixtures are data only (inputs + expected outputs). Usage:
+    python tools/gen_golden.py            # writes tests/golden/*.npz
+"""
+import importlib.util
+import os
+import sys
+from types import SimpleNamespace
+
+os.environ.setdefault("PYTHONDONTWRITEBYTECODE", "1")
+sys.dont_write_bytecode = True
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, os.path.join(HERE, "_stubs"))
+sys.path.insert(1, "/root/reference")
+sys.path.insert(2, "/root/reference/deqmpc")
+
+import numpy as np
+import torch
+
+torch.set_num_threads(8)
+
+from qpth import AL_mpc, al_utils  # noqa: E402  (the reference)
+
+spec = importlib.util.spec_from_file_location(
+    "problems", os.path.join(ROOT, "deq-mpc-corl_amd", "problems.py"))
+problems = importlib.util.module_from_spec(spec)
+spec.loader.exec_module(problems)
+
+OUT = os.path.join(ROOT, "tests", "golden")
+
+
+class Recorder:
+    """Hooks the reference's inner functions and logs what they compute."""
+
+    def __init__(self, T, n, record_H=True):
+        self.T, self.n = T, n
+        self.record_H = record_H
+        self.steps = []          # one dict per Newton step
+        self.newton_per_al = []  # Newton steps per NewtonAL.apply
+        self._orig_gh = al_utils.merit_grad_hessian
+        self._orig_ls = al_utils.line_search_newton
+        self._orig_apply = al_utils.NewtonAL.apply
+
+    def __enter__(self):
+        rec = self
+
+        def gh(*a, **k):
+            grad, H, H2 = rec._orig_gh(*a, **k)
+            st = {"g": grad.detach().clone()}
+            first = rec.newton_per_al[-1] == 0
+            rec.newton_per_al[-1] += 1
+            if rec.record_H and first:
+                st["H"] = H.detach().clone()
+            rec.steps.append(st)
+            return grad, H, H2
+
+        def ls(update, x_est, meritfnQ, merit, x0):
+            box = {}
+
+            def mf(x):
+                out = meritfnQ(x)
+                if x.dim() == 4:
+                    box["phi"] = out.detach().reshape(20, -1).clone()
+                return out
+
+            x_new, new_merit, stepsz, status = rec._orig_ls(update, x_est, mf, merit, x0)
+            st = rec.steps[-1]
+            st["d"] = update.detach().clone()
+            st["phi_prev"] = merit.detach().clone()
+            st["phi"] = box["phi"]
+            st["k"] = torch.min(box["phi"], dim=0).indices.clone()
+            st["accept"] = status.detach().clone()
+            st["z"] = x_new.detach().clone()
+            return x_new, new_merit, stepsz, status
+
+        def apply(*a):
+            rec.newton_per_al.append(0)
+            return rec._orig_apply(*a)
+
+        al_utils.merit_grad_hessian = gh
+        al_utils.line_search_newton = ls
+        al_utils.NewtonAL.apply = staticmethod(apply)
+        return self
+
+    def __exit__(self, *exc):
+        al_utils.merit_grad_hessian = self._orig_gh
+        al_utils.line_search_newton = self._orig_ls
+        al_utils.NewtonAL.apply = self._orig_apply
+
+    def band(self, H):
+        """[B,N,N] dense -> diag blocks [B,T,n,n], sub-diag blocks [B,T-1,n,n]."""
+        T, n = self.T, self.n
+        B = H.shape[0]
+        Hb = H.reshape(B, T, n, T, n)
+        diag = torch.stack([Hb[:, t, :, t, :] for t in range(T)], dim=1)
+        sub = torch.stack([Hb[:, t + 1, :, t, :] for t in range(T - 1)], dim=1)
+        mask = torch.ones(T, T, dtype=torch.bool)
+        for t in range(T):
+            mask[t, t] = False
+            if t + 1 < T:
+                mask[t + 1, t] = False
+                mask[t, t + 1] = False
+        off = Hb.permute(0, 1, 3, 2, 4)[:, mask]
+        assert float(off.abs().max()) == 0.0, "Hessian has entries outside the band"
+        return diag, sub
+
+
+def np_(t):
+    return t.detach().cpu().numpy()
+
+
+def run_case(name, B, T, nx, nu, dtype, al_iter, active=False, seed=0,
+             backward=False, nonlinear=False, n_record_steps=None):
+    n = nx + nu
+    p = problems.synthetic_problem(B, T, nx, nu, seed=seed, dtype=dtype, active=active)
+    if nonlinear:
+        dyn = problems.PendulumDynamics()
+    else:
+        dyn = problems.AffineDynamics(p.F, p.c)
+    Qd = p.Qd.clone()
+    q = p.q.clone()
+    if backward:
+        Qd.requires_grad_(True)
+        q.requires_grad_(True)
+    C = torch.diag_embed(Qd)
+    cost = al_utils.QuadCost(C, q, torch.zeros(B, T, dtype=dtype))
+    mpc = AL_mpc.MPC(nx, nu, T, u_lower=p.u_lo, u_upper=p.u_hi, n_batch=B, dtype=dtype)
+    mpc.reinitialize(p.x0, None)
+    mpc.al_iter = al_iter
+    rec = Recorder(T, n)
+    with rec:
+        x, u, status = mpc(p.x0, cost, dyn, dyn.jac,
+                           x_init=p.z0[..., :nx].clone(), u_init=p.z0[..., nx:].clone())
+    out = {
+        "B": B, "T": T, "nx": nx, "nu": nu, "al_iter": al_iter,
+        "dtype": "f64" if dtype == torch.float64 else "f32",
+        "nonlinear": int(nonlinear), "active": int(active), "seed": seed,
+        "Qd": np_(p.Qd), "q": np_(p.q), "F": np_(p.F), "c": np_(p.c), "x0": np_(p.x0),
+        "u_lo": np_(p.u_lo), "u_hi": np_(p.u_hi), "z0": np_(p.z0),
+        "x": np_(x), "u": np_(u), "status": int(bool(status)),
+        "newton_per_al": np.array(rec.newton_per_al, dtype=np.int32),
+        "lam_final": np_(mpc.lamda_prev), "rho_final": np_(mpc.rho_prev),
+        "lam_hist": np.stack([np_(l) for l in mpc.cost_lam_hist[1][1:]]),
+        "rho_hist": np.stack([np_(r) for r in mpc.cost_lam_hist[2][1:]]),
+    }
+    steps = rec.steps if n_record_steps is None else rec.steps[:n_record_steps]
+    out["n_steps_recorded"] = len(steps)
+    for key in ("g", "d", "phi", "phi_prev", "k", "accept", "z"):
+        out["step_" + key] = np.stack([np_(s[key]) for s in steps])
+    hidx, hd, hs = [], [], []
+    for i, s in enumerate(steps):
+        if "H" in s:
+            d_, s_ = rec.band(s["H"])
+            hidx.append(i); hd.append(np_(d_)); hs.append(np_(s_))
+    out["H_step_index"] = np.array(hidx, dtype=np.int32)
+    out["H_diag"] = np.stack(hd)
+    out["H_sub"] = np.stack(hs)
+    if backward:
+        g = torch.Generator().manual_seed(1234)
+        wx = torch.randn(B, T, nx, generator=g, dtype=torch.float32)
+        wu = torch.randn(B, T, nu, generator=g, dtype=torch.float32)
+        loss = (x * wx).sum() + (u * wu).sum()
+        loss.backward()
+        out["bwd_wx"] = np_(wx); out["bwd_wu"] = np_(wu)
+        out["bwd_q_grad"] = np_(q.grad); out["bwd_Qd_grad"] = np_(Qd.grad)
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **out)
+    full = all(k == 4 for k in rec.newton_per_al)
+    print(f"{name}: newton_per_al={rec.newton_per_al} fixed4={full} "
+          f"accept_frac={float(np.mean(out['step_accept'])):.2f} "
+          f"k_max={int(out['step_k'].max())} size={os.path.getsize(path)/1024:.0f}KB")
+    return out
+
+
+def run_state_carry(name, B, T, nx, nu, dtype, calls=3):
+    """reinitialize + successive __call__s: pins lamda/rho carry and rho growth
+    (AL_mpc.py:256-257, 333-335) the way policies.Tracking_MPC drives the solver
+    (policies.py:1242-1244, 1262, 1274)."""
+    p = problems.synthetic_problem(B, T, nx, nu, seed=7, dtype=dtype)
+    dyn = problems.AffineDynamics(p.F, p.c)
+    C = torch.diag_embed(p.Qd)
+    mpc = AL_mpc.MPC(nx, nu, T, u_lower=p.u_lo, u_upper=p.u_hi, n_batch=B, dtype=dtype)
+    mpc.reinitialize(p.x0, None)
+    mpc.x_init = p.z0[..., :nx].clone()
+    mpc.u_init = p.z0[..., nx:].clone()
+    out = {"B": B, "T": T, "nx": nx, "nu": nu, "calls": calls,
+           "dtype": "f64" if dtype == torch.float64 else "f32",
+           "Qd": np_(p.Qd), "F": np_(p.F), "c": np_(p.c), "x0": np_(p.x0),
+           "u_lo": np_(p.u_lo), "u_hi": np_(p.u_hi), "z0": np_(p.z0)}
+    g = torch.Generator().manual_seed(99)
+    qs, xs, us, lams, rhos, npa = [], [], [], [], [], []
+    for i in range(calls):
+        # the network would move the reference a little between DEQ iterations
+        xref = p.xref + 0.05 * i * torch.randn(B, T, nx + nu, generator=g, dtype=dtype)
+        xref[..., nx:] = 0
+        q = -(p.Qd * xref)
+        cost = al_utils.QuadCost(C, q, torch.zeros(B, T, dtype=dtype))
+        mpc.al_iter = 2
+        rec = Recorder(T, nx + nu, record_H=False)
+        with rec:
+            x, u, status = mpc(p.x0, cost, dyn, dyn.jac)
+        qs.append(np_(q)); xs.append(np_(x)); us.append(np_(u))
+        lams.append(np_(mpc.lamda_prev)); rhos.append(np_(mpc.rho_prev))
+        npa.append(rec.newton_per_al)
+    out.update(q=np.stack(qs), x=np.stack(xs), u=np.stack(us),
+               lam=np.stack(lams), rho=np.stack(rhos),
+               newton_per_al=np.array(npa, dtype=np.int32))
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **out)
+    print(f"{name}: newton_per_al={npa} rho={[float(r.max()) for r in rhos]}")
+
+
+def run_tracking_mpc(name, B, T, nx, nu):
+    """policies.Tracking_MPC end to end with a fake env/args (the adapter row of
+    SURVEY.md §8b); falls back silently if policies.py cannot be imported."""
+    try:
+        import policies  # noqa: F401  (reference, deqmpc/policies.py)
+    except Exception as e:  # pragma: no cover
+        print("Tracking_MPC trace skipped:", repr(e))
+        return
+    dtype = torch.float64
+    p = problems.synthetic_problem(B, T, nx, nu, seed=11, dtype=dtype)
+    dyn = problems.AffineDynamics(p.F, p.c)
+    env = SimpleNamespace(
+        nu=nu, nx=nx, nq=nx // 2, dt=0.05, dynamics=dyn, dynamics_derivatives=dyn.jac,
+        action_space=SimpleNamespace(high=np.full(nu, 0.5), low=np.full(nu, -0.5)))
+    args = SimpleNamespace(
+        T=T, device="cpu", qp_iter=1, eps=1e-2, warm_start=False, bsz=B,
+        Q=torch.tensor([10.0] * nx), R=torch.tensor([1e-8] * nu), dtype="double",
+        solver_type="al", env="synthetic")
+    torch.manual_seed(5)
+    tm = policies.Tracking_MPC(args, env)
+    x_ref = p.xref[..., :nx].clone()
+    u_ref = p.xref[..., nx:].clone()
+    tm.reinitialize(x_ref, torch.ones(B, T, 1, dtype=dtype))
+    xs, us, xrefs = [], [], []
+    g = torch.Generator().manual_seed(3)
+    for i in range(3):
+        xr = x_ref + 0.05 * i * torch.randn(B, T, nx, generator=g, dtype=dtype)
+        x, u, status = tm(p.x0, None, xr, u_ref, al_iters=2)
+        xs.append(np_(x)); us.append(np_(u)); xrefs.append(np_(xr))
+    out = {"B": B, "T": T, "nx": nx, "nu": nu, "F": np_(p.F), "c": np_(p.c),
+           "x0": np_(p.x0), "x_ref": np.stack(xrefs), "u_ref": np_(u_ref),
+           "x": np.stack(xs), "u": np.stack(us),
+           "lam": np_(tm.ctrl.lamda_prev), "rho": np_(tm.ctrl.rho_prev)}
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+    print(f"{name}: ok rho={float(tm.ctrl.rho_prev.max())}")
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    f64, f32 = torch.float64, torch.float32
+    shapes = [("pend", 8, 5, 2, 1), ("cart", 8, 10, 8, 2), ("quad13", 4, 20, 13, 4),
+              ("quad12", 4, 20, 12, 4), ("fcp14", 2, 10, 14, 4)]
+    for tag, B, T, nx, nu in shapes:
+        run_case(f"{tag}_f64_al2", B, T, nx, nu, f64, 2, backward=(tag in ("pend", "cart")))
+        run_case(f"{tag}_f32_al2", B, T, nx, nu, f32, 2)
+    # branch coverage: many active bounds, deeper AL (rho up to 1e5), fp64 only
+    run_case("pend_active_f64_al6", 8, 5, 2, 1, f64, 6, active=True, backward=True)
+    run_case("cart_active_f64_al6", 8, 10, 8, 2, f64, 6, active=True)
+    run_case("quad13_active_f64_al2", 4, 20, 13, 4, f64, 2, active=True, n_record_steps=8)
+    run_case("quad13_active_f32_al2", 4, 20, 13, 4, f32, 2, active=True, n_record_steps=8)
+    # deep solve where the reference's batch-global early exit fires
+    run_case("pend_f64_al10", 8, 5, 2, 1, f64, 10)
+    # nonlinear-caller mode
+    run_case("pend_nonlin_f64_al4", 8, 5, 2, 1, f64, 4, nonlinear=True, backward=True)
+    run_case("pend_nonlin_f32_al2", 8, 5, 2, 1, f32, 2, nonlinear=True)
+    run_state_carry("cart_carry_f64", 8, 10, 8, 2, f64)
+    run_tracking_mpc("cart_tracking_f64", 8, 10, 8, 2)
+
+
+if __name__ == "__main__":
+    main()
