@@ -1,0 +1,94 @@
+"""ctypes binding of libmi_alqp.so (include/mi_alqp.h).
+
+The library is built in-tree by ``__graft_entry__.build()`` /
+``deq-mpc-corl_amd/csrc/build.sh`` with hipcc for gfx950. There is NO fallback:
+if the shared object is missing this module raises, and so does every solver
+entry point (the product path never routes through a CPU implementation).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libmi_alqp.so")
+
+ABI_VERSION = 1
+
+
+class AlqpDims(C.Structure):
+    _fields_ = [("B", C.c_int), ("T", C.c_int), ("nx", C.c_int), ("nu", C.c_int)]
+
+
+class AlqpParams(C.Structure):
+    _fields_ = [("al_iter", C.c_int), ("max_newton", C.c_int), ("n_ls", C.c_int),
+                ("flags", C.c_int), ("rho_scale", C.c_double)]
+
+
+class AlqpTrace(C.Structure):
+    _fields_ = [("g", C.c_void_p), ("d", C.c_void_p), ("phi", C.c_void_p),
+                ("phi_prev", C.c_void_p), ("k", C.c_void_p), ("accept", C.c_void_p)]
+
+
+ALQP_INIT_MERIT = 1
+ALQP_DUAL_UPDATE = 2
+ALQP_SAVE_FACTOR = 4
+
+ERRORS = {-1: "bad argument", -2: "unsupported (nx, nu) or horizon does not fit in LDS",
+          -3: "kernel launch failed"}
+
+_P = C.c_void_p
+_SIGS = {
+    # name: (restype, argtypes) ; the f32/f64 pairs share a signature
+    "alqp_solve_lin": (C.c_int, [C.POINTER(AlqpDims), C.POINTER(AlqpParams), _P, _P, _P, _P, _P, _P, _P,
+                                 C.c_long, C.c_long, _P, _P, _P, _P, _P, _P, _P, _P,
+                                 C.POINTER(AlqpTrace), _P]),
+    "alqp_newton_step": (C.c_int, [C.POINTER(AlqpDims), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P,
+                                   C.c_long, C.c_long, _P, _P, _P, _P, _P]),
+    "alqp_merit": (C.c_int, [C.POINTER(AlqpDims), C.c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P,
+                             C.c_long, C.c_long, _P, _P, _P]),
+    "alqp_linesearch_pick": (C.c_int, [C.POINTER(AlqpDims), C.c_int, _P, _P, _P, _P, _P, _P, _P]),
+    "alqp_dual_update": (C.c_int, [C.POINTER(AlqpDims), _P, _P, _P, _P, _P, C.c_long, C.c_long, _P, _P,
+                                   C.c_double, _P]),
+    "alqp_backward": (C.c_int, [C.POINTER(AlqpDims), _P, _P, _P, _P, _P, _P, _P, _P]),
+}
+_PLAIN = {
+    "alqp_abi_version": (C.c_int, []),
+    "alqp_supported": (C.c_int, [C.POINTER(AlqpDims), C.c_int]),
+    "alqp_lds_bytes": (C.c_size_t, [C.POINTER(AlqpDims), C.c_int]),
+    "alqp_qps_per_wave": (C.c_int, [C.POINTER(AlqpDims), C.c_int]),
+}
+
+EXPORTED_SYMBOLS = sorted([f"{n}_{s}" for n in _SIGS for s in ("f32", "f64")] + list(_PLAIN))
+
+_lib = None
+
+
+def load():
+    """Load libmi_alqp.so (once). Raises RuntimeError when it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"mi_alqp: HIP extension not built ({LIB_PATH} missing). Run "
+            "`python -c 'import __graft_entry__ as g; g.build()'` - there is no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in _SIGS.items():
+        for sfx in ("f32", "f64"):
+            fn = getattr(lib, f"{name}_{sfx}")
+            fn.restype = res
+            fn.argtypes = args
+    for name, (res, args) in _PLAIN.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    if lib.alqp_abi_version() != ABI_VERSION:
+        raise RuntimeError("mi_alqp: libmi_alqp.so ABI version mismatch - rebuild the extension")
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        raise RuntimeError(f"mi_alqp: {what} failed: {ERRORS.get(rc, rc)}")

@@ -1,0 +1,156 @@
+"""Device backend: torch tensors -> raw device pointers -> libmi_alqp.so.
+
+PyTorch is plumbing here (allocator, streams); every number is produced by the
+hand-written gfx950 kernels in csrc/. All methods enqueue on torch's current HIP
+stream and never synchronise.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import _lib
+
+
+def _dt(t):
+    if t.dtype == torch.float32:
+        return "f32"
+    if t.dtype == torch.float64:
+        return "f64"
+    raise TypeError(f"mi_alqp: unsupported dtype {t.dtype}")
+
+
+def _ptr(t, name, dtype=None, allow_none=False):
+    if t is None:
+        if allow_none:
+            return None
+        raise ValueError(f"mi_alqp: {name} is required")
+    if not t.is_cuda:
+        raise RuntimeError(
+            f"mi_alqp: {name} lives on {t.device}; the solver only runs on a ROCm device "
+            "(no CPU fallback)")
+    if not t.is_contiguous():
+        raise ValueError(f"mi_alqp: {name} must be contiguous")
+    if dtype is not None and t.dtype != dtype:
+        raise TypeError(f"mi_alqp: {name} has dtype {t.dtype}, expected {dtype}")
+    return C.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class HipBackend:
+    """The product backend: thin argument marshalling over the C ABI."""
+
+    name = "hip"
+
+    def __init__(self):
+        self.lib = _lib.load()
+
+    # -- queries ---------------------------------------------------------------
+    def supported(self, B, T, nx, nu, dtype):
+        d = _lib.AlqpDims(B, T, nx, nu)
+        return bool(self.lib.alqp_supported(C.byref(d), int(dtype == torch.float64)))
+
+    def lds_bytes(self, B, T, nx, nu, dtype):
+        d = _lib.AlqpDims(B, T, nx, nu)
+        return int(self.lib.alqp_lds_bytes(C.byref(d), int(dtype == torch.float64)))
+
+    def qps_per_wave(self, B, T, nx, nu, dtype):
+        d = _lib.AlqpDims(B, T, nx, nu)
+        return int(self.lib.alqp_qps_per_wave(C.byref(d), int(dtype == torch.float64)))
+
+    # -- kernels -----------------------------------------------------------------
+    def solve_lin(self, dims, Qd, q, F, c, x0, ulo, uhi, sb_u, st_u, z, lam, rho, phi,
+                  rnorm2=None, info=None, status=None, factor=None, al_iter=2, max_newton=4,
+                  n_ls=20, flags=_lib.ALQP_INIT_MERIT | _lib.ALQP_DUAL_UPDATE, rho_scale=10.0,
+                  trace=None):
+        B, T, nx, nu = dims
+        dt = z.dtype
+        sfx = _dt(z)
+        d = _lib.AlqpDims(B, T, nx, nu)
+        p = _lib.AlqpParams(al_iter, max_newton, n_ls, flags, rho_scale)
+        tr = None
+        if trace is not None:
+            tr = _lib.AlqpTrace(*[
+                (trace[k].data_ptr() if trace.get(k) is not None else None)
+                for k in ("g", "d", "phi", "phi_prev", "k", "accept")])
+        fn = getattr(self.lib, "alqp_solve_lin_" + sfx)
+        rc = fn(C.byref(d), C.byref(p), _ptr(Qd, "Qd", dt), _ptr(q, "q", dt), _ptr(F, "F", dt),
+                _ptr(c, "c", dt), _ptr(x0, "x0", dt), _ptr(ulo, "u_lower", dt), _ptr(uhi, "u_upper", dt),
+                sb_u, st_u, _ptr(z, "z", dt), _ptr(lam, "lam", dt), _ptr(rho, "rho", dt),
+                _ptr(phi, "phi", dt), _ptr(rnorm2, "rnorm2", dt, True),
+                _ptr(info, "info", torch.int32, True), _ptr(status, "status", torch.uint8, True),
+                _ptr(factor, "factor", dt, True), C.byref(tr) if tr is not None else None, _stream())
+        _lib.check(rc, "alqp_solve_lin_" + sfx)
+
+    def newton_step(self, dims, z, xnext, F, x0, lam, rho, Qd, q, ulo, uhi, sb_u, st_u, d_out,
+                    g_out=None, factor=None, info=None):
+        B, T, nx, nu = dims
+        dt = z.dtype
+        sfx = _dt(z)
+        d = _lib.AlqpDims(B, T, nx, nu)
+        fn = getattr(self.lib, "alqp_newton_step_" + sfx)
+        rc = fn(C.byref(d), _ptr(z, "z", dt), _ptr(xnext, "xnext", dt), _ptr(F, "F", dt),
+                _ptr(x0, "x0", dt), _ptr(lam, "lam", dt), _ptr(rho, "rho", dt), _ptr(Qd, "Qd", dt),
+                _ptr(q, "q", dt), _ptr(ulo, "u_lower", dt), _ptr(uhi, "u_upper", dt), sb_u, st_u,
+                _ptr(d_out, "d_out", dt), _ptr(g_out, "g_out", dt, True),
+                _ptr(factor, "factor", dt, True), _ptr(info, "info", torch.int32, True), _stream())
+        _lib.check(rc, "alqp_newton_step_" + sfx)
+
+    def merit(self, dims, K, zc, xnext, x0, lam, rho, Qd, q, ulo, uhi, sb_u, st_u, phi, rnorm2=None):
+        B, T, nx, nu = dims
+        dt = zc.dtype
+        sfx = _dt(zc)
+        d = _lib.AlqpDims(B, T, nx, nu)
+        fn = getattr(self.lib, "alqp_merit_" + sfx)
+        rc = fn(C.byref(d), K, _ptr(zc, "zc", dt), _ptr(xnext, "xnext", dt), _ptr(x0, "x0", dt),
+                _ptr(lam, "lam", dt), _ptr(rho, "rho", dt), _ptr(Qd, "Qd", dt), _ptr(q, "q", dt),
+                _ptr(ulo, "u_lower", dt), _ptr(uhi, "u_upper", dt), sb_u, st_u,
+                _ptr(phi, "phi", dt), _ptr(rnorm2, "rnorm2", dt, True), _stream())
+        _lib.check(rc, "alqp_merit_" + sfx)
+
+    def linesearch_pick(self, dims, n_ls, phi, phi_prev, d, z, k_out=None, accept_out=None):
+        B, T, nx, nu = dims
+        dt = z.dtype
+        sfx = _dt(z)
+        dd = _lib.AlqpDims(B, T, nx, nu)
+        fn = getattr(self.lib, "alqp_linesearch_pick_" + sfx)
+        rc = fn(C.byref(dd), n_ls, _ptr(phi, "phi", dt), _ptr(phi_prev, "phi_prev", dt),
+                _ptr(d, "d", dt), _ptr(z, "z", dt), _ptr(k_out, "k_out", torch.int32, True),
+                _ptr(accept_out, "accept_out", torch.int32, True), _stream())
+        _lib.check(rc, "alqp_linesearch_pick_" + sfx)
+
+    def dual_update(self, dims, z, xnext, x0, ulo, uhi, sb_u, st_u, lam, rho, rho_scale=10.0):
+        B, T, nx, nu = dims
+        dt = z.dtype
+        sfx = _dt(z)
+        d = _lib.AlqpDims(B, T, nx, nu)
+        fn = getattr(self.lib, "alqp_dual_update_" + sfx)
+        rc = fn(C.byref(d), _ptr(z, "z", dt), _ptr(xnext, "xnext", dt), _ptr(x0, "x0", dt),
+                _ptr(ulo, "u_lower", dt), _ptr(uhi, "u_upper", dt), sb_u, st_u,
+                _ptr(lam, "lam", dt), _ptr(rho, "rho", dt), rho_scale, _stream())
+        _lib.check(rc, "alqp_dual_update_" + sfx)
+
+    def backward(self, dims, factor, F, rho, z_final, gbar, q_grad, Qd_grad):
+        B, T, nx, nu = dims
+        dt = gbar.dtype
+        sfx = _dt(gbar)
+        d = _lib.AlqpDims(B, T, nx, nu)
+        fn = getattr(self.lib, "alqp_backward_" + sfx)
+        rc = fn(C.byref(d), _ptr(factor, "factor", dt), _ptr(F, "F", dt), _ptr(rho, "rho", dt),
+                _ptr(z_final, "z_final", dt), _ptr(gbar, "gbar", dt), _ptr(q_grad, "q_grad", dt),
+                _ptr(Qd_grad, "Qd_grad", dt), _stream())
+        _lib.check(rc, "alqp_backward_" + sfx)
+
+
+_default = None
+
+
+def default_backend():
+    global _default
+    if _default is None:
+        _default = HipBackend()
+    return _default

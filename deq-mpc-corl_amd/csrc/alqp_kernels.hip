@@ -1,0 +1,569 @@
+// alqp_kernels.hip - gfx950 kernels + the C ABI of include/mi_alqp.h.
+//
+// Build: hipcc --offload-arch=gfx950 -O3 -shared -fPIC -I../../include alqp_kernels.hip -o libmi_alqp.so
+// No torch types anywhere: plain device pointers in, kernel launches on the caller's stream.
+#include <hip/hip_runtime.h>
+
+#include "alqp_team.hpp"
+#include "mi_alqp.h"
+
+namespace alqp {
+
+template <typename real>
+struct SolveArgs {
+    int B, T;
+    int al_iter, max_newton, n_ls, flags;
+    real rho_scale;
+    const real *Qd, *q, *F, *c, *x0, *ulo, *uhi, *xnext;
+    long sb_u, st_u;
+    real *z, *lam, *rho, *phi, *rnorm2;
+    int *info;
+    unsigned char *status;
+    real *factor;
+    // trace
+    real *tr_g, *tr_d, *tr_phi, *tr_phi_prev;
+    int *tr_k, *tr_accept;
+    // newton_step / backward extras
+    real *d_out, *g_out;
+    const real *gbar, *z_final;
+    real *q_grad, *Qd_grad;
+};
+
+template <typename real, int NX, int NU>
+__device__ inline void bind_instance(Team<real, NX, NU> &tm, const SolveArgs<real> &a, int b) {
+    constexpr int N = NX + NU;
+    const int T = a.T;
+    tm.gQd = a.Qd ? a.Qd + (size_t)b * T * N : nullptr;
+    tm.gq = a.q ? a.q + (size_t)b * T * N : nullptr;
+    tm.gF = a.F ? a.F + (size_t)b * (T - 1) * NX * N : nullptr;
+    tm.gc = a.c ? a.c + (size_t)b * (T - 1) * NX : nullptr;
+    tm.gx0 = a.x0 ? a.x0 + (size_t)b * NX : nullptr;
+    tm.gulo = a.ulo ? a.ulo + (size_t)b * a.sb_u : nullptr;
+    tm.guhi = a.uhi ? a.uhi + (size_t)b * a.sb_u : nullptr;
+    tm.st_u = a.st_u;
+    tm.gxnext = a.xnext ? a.xnext + (size_t)b * (T - 1) * NX : nullptr;
+}
+
+// ---- fused LinDx solve -------------------------------------------------------------
+template <typename real, int NX, int NU>
+__global__ __launch_bounds__(64) void k_solve_lin(SolveArgs<real> a) {
+    using C = Cfg<real, NX, NU>;
+    constexpr int G = C::G, N = C::N;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    real *smem = reinterpret_cast<real *>(smem_raw);
+    const int lane = threadIdx.x, team = lane / G, li = lane % G;
+    const int b_raw = blockIdx.x * C::QPW + team;
+    const bool active = b_raw < a.B;
+    const int b = active ? b_raw : a.B - 1;
+    const int T = a.T, M = C::M(T), neq = T * NX;
+
+    Team<real, NX, NU> tm;
+    tm.init(smem + (size_t)team * C::team_words(T), li, team * G, T, b);
+    bind_instance(tm, a, b);
+
+    real *gz = a.z + (size_t)b * T * N;
+    real *glam = a.lam + (size_t)b * M;
+    for (int e = li; e < T * N; e += G) tm.zs[e] = gz[e];
+    for (int e = li; e < M; e += G) tm.lams[e] = glam[e];
+    tm.rho = a.rho[b];
+    real phi_prev = a.phi[b];
+    wave_sync();
+    tm.residual_sweep();
+
+    int step_id = 0;
+    for (int it = 0; it < a.al_iter; ++it) {
+        if (a.flags & ALQP_INIT_MERIT) {
+            real p1[1];
+            tm.template merit_candidates<1>(p1, true);
+            phi_prev = p1[0];
+        }
+        for (int st = 0; st < a.max_newton; ++st, ++step_id) {
+            real *tg = a.tr_g ? a.tr_g + ((size_t)step_id * a.B + b) * T * N : nullptr;
+            tm.forward_sweep(active ? tg : nullptr);
+            tm.backward_sweep();
+            if (a.tr_d && active) {
+                real *td = a.tr_d + ((size_t)step_id * a.B + b) * T * N;
+                for (int e = li; e < T * N; e += G) td[e] = tm.ds[e];
+            }
+            real ph[20];
+            tm.template merit_candidates<20>(ph, false);
+            int kbest = 0;
+            real best = ph[0];
+#pragma unroll
+            for (int k = 1; k < 20; ++k) {
+                if (k < a.n_ls && !(best != best) && (ph[k] != ph[k] || ph[k] < best)) {
+                    best = ph[k];
+                    kbest = k;
+                }
+            }
+            const bool acc = best < phi_prev;
+            if (active && li == 0) {
+                if (a.tr_phi)
+#pragma unroll
+                    for (int k = 0; k < 20; ++k)
+                        if (k < a.n_ls) a.tr_phi[((size_t)step_id * a.n_ls + k) * a.B + b] = ph[k];
+                if (a.tr_phi_prev) a.tr_phi_prev[(size_t)step_id * a.B + b] = phi_prev;
+                if (a.tr_k) a.tr_k[(size_t)step_id * a.B + b] = kbest;
+                if (a.tr_accept) a.tr_accept[(size_t)step_id * a.B + b] = acc ? 1 : 0;
+            }
+            const real alpha = acc ? real(1) / real(1 << kbest) : real(0);
+            for (int e = li; e < T * N; e += G) tm.zs[e] += alpha * tm.ds[e];
+            for (int e = li; e < neq; e += G) tm.req[e] += alpha * tm.seq[e];
+            wave_sync();
+            phi_prev = best;  // merit <- new_merit even when rejected (al_utils.py:569)
+        }
+        if (a.flags & ALQP_DUAL_UPDATE) {
+            tm.dual_update();
+            tm.rho *= a.rho_scale;
+        }
+    }
+
+    const real rn2 = tm.rplus2();
+    int bad = 0;
+    for (int e = li; e < T * N; e += G) {
+        real v = tm.zs[e];
+        bad |= !(v - v == real(0));
+    }
+    bad = team_or<G>(bad);
+    if (active) {
+        for (int e = li; e < T * N; e += G) gz[e] = tm.zs[e];
+        for (int e = li; e < M; e += G) glam[e] = tm.lams[e];
+        if ((a.flags & ALQP_SAVE_FACTOR) && a.factor) {
+            real *gf = a.factor + (size_t)b * T * C::XT;
+            for (int e = li; e < T * C::XT; e += G) gf[e] = tm.Xp[e];
+        }
+        if (li == 0) {
+            a.rho[b] = tm.rho;
+            a.phi[b] = phi_prev;
+            if (a.rnorm2) a.rnorm2[b] = rn2;
+            if (a.info) a.info[b] = tm.info;
+            if (a.status) a.status[b] = bad ? 0 : 1;
+        }
+    }
+}
+
+// ---- one Newton direction (nonlinear-caller mode) ----------------------------------
+template <typename real, int NX, int NU>
+__global__ __launch_bounds__(64) void k_newton_step(SolveArgs<real> a) {
+    using C = Cfg<real, NX, NU>;
+    constexpr int G = C::G, N = C::N;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    real *smem = reinterpret_cast<real *>(smem_raw);
+    const int lane = threadIdx.x, team = lane / G, li = lane % G;
+    const int b_raw = blockIdx.x * C::QPW + team;
+    const bool active = b_raw < a.B;
+    const int b = active ? b_raw : a.B - 1;
+    const int T = a.T, M = C::M(T);
+
+    Team<real, NX, NU> tm;
+    tm.init(smem + (size_t)team * C::team_words(T), li, team * G, T, b);
+    bind_instance(tm, a, b);
+    const real *gz = a.z + (size_t)b * T * N;
+    const real *glam = a.lam + (size_t)b * M;
+    for (int e = li; e < T * N; e += G) tm.zs[e] = gz[e];
+    for (int e = li; e < M; e += G) tm.lams[e] = glam[e];
+    tm.rho = a.rho[b];
+    wave_sync();
+    tm.forward_sweep((active && a.g_out) ? a.g_out + (size_t)b * T * N : nullptr);
+    tm.backward_sweep();
+    if (active) {
+        real *gd = a.d_out + (size_t)b * T * N;
+        for (int e = li; e < T * N; e += G) gd[e] = tm.ds[e];
+        if (a.factor) {
+            real *gf = a.factor + (size_t)b * T * C::XT;
+            for (int e = li; e < T * C::XT; e += G) gf[e] = tm.Xp[e];
+        }
+        if (li == 0 && a.info) a.info[b] = tm.info;
+    }
+}
+
+// ---- backward of the implicit layer -------------------------------------------------
+template <typename real, int NX, int NU>
+__global__ __launch_bounds__(64) void k_backward(SolveArgs<real> a) {
+    using C = Cfg<real, NX, NU>;
+    constexpr int G = C::G, N = C::N;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    real *smem = reinterpret_cast<real *>(smem_raw);
+    const int lane = threadIdx.x, team = lane / G, li = lane % G;
+    const int b_raw = blockIdx.x * C::QPW + team;
+    const bool active = b_raw < a.B;
+    const int b = active ? b_raw : a.B - 1;
+    const int T = a.T;
+
+    Team<real, NX, NU> tm;
+    tm.init(smem + (size_t)team * C::team_words(T), li, team * G, T, b);
+    bind_instance(tm, a, b);
+    const real *gf = a.factor + (size_t)b * T * C::XT;
+    const real *gg = a.gbar + (size_t)b * T * N;
+    for (int e = li; e < T * C::XT; e += G) tm.Xp[e] = gf[e];
+    for (int e = li; e < T * N; e += G) tm.ds[e] = -gg[e];
+    tm.rho = a.rho[b];
+    wave_sync();
+    tm.forward_solve_only();
+    tm.backward_sweep();
+    if (active) {
+        const real *zf = a.z_final + (size_t)b * T * N;
+        real *qg = a.q_grad + (size_t)b * T * N;
+        real *Qg = a.Qd_grad + (size_t)b * T * N;
+        for (int e = li; e < T * N; e += G) {
+            real w = tm.ds[e];
+            qg[e] = w;
+            Qg[e] = w * zf[e];
+        }
+    }
+}
+
+// ---- size-generic helper kernels (one wavefront per instance) ----------------------
+template <typename real>
+__device__ inline real wave_sum(real v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+template <typename real>
+struct AuxArgs {
+    int B, T, nx, nu, K, n_ls;
+    const real *zc, *xnext, *x0, *lam, *rho, *Qd, *q, *ulo, *uhi;
+    long sb_u, st_u;
+    real *phi, *rnorm2;
+    // pick
+    const real *phi_all, *d;
+    real *phi_prev, *z;
+    int *k_out, *accept_out;
+    // dual
+    real *lam_io, *rho_io;
+    real rho_scale;
+};
+
+// merit of candidate kk for instance b (al_utils.py:73-77), block = (kk, b)
+template <typename real>
+__global__ __launch_bounds__(64) void k_merit(AuxArgs<real> a) {
+    const int lane = threadIdx.x;
+    const int b = blockIdx.x % a.B, kk = blockIdx.x / a.B;
+    const int T = a.T, nx = a.nx, nu = a.nu, n = nx + nu, neq = T * nx;
+    const real *z = a.zc + ((size_t)kk * a.B + b) * T * n;
+    const real *xn = a.xnext + ((size_t)kk * a.B + b) * (T - 1) * nx;
+    const real *lam = a.lam + (size_t)b * (neq + 2 * T * nu);
+    const real *Qd = a.Qd + (size_t)b * T * n, *q = a.q + (size_t)b * T * n;
+    const real *ulo = a.ulo + (size_t)b * a.sb_u, *uhi = a.uhi + (size_t)b * a.sb_u;
+    const real rho = a.rho[b];
+    real acc = 0, sq = 0;
+    for (int e = lane; e < T * n; e += 64) {
+        int t = e / n, j = e - t * n;
+        real v = z[e];
+        acc += (real(0.5) * Qd[e] * v + q[e]) * v;
+        if (j >= nx) {
+            int ju = j - nx;
+            real vu = v - uhi[t * a.st_u + ju], vl = -v + ulo[t * a.st_u + ju];
+            real cu = vu > 0 ? vu : real(0), cl = vl > 0 ? vl : real(0);
+            int ru = neq + t * 2 * nu + ju;
+            acc += lam[ru] * vu + lam[ru + nu] * vl;
+            sq += cu * cu + cl * cl;
+        }
+    }
+    for (int e = lane; e < neq; e += 64) {
+        int t = e / nx, i = e - t * nx;
+        real r = (t < T - 1) ? z[(t + 1) * n + i] - xn[t * nx + i] : z[i] - a.x0[(size_t)b * nx + i];
+        acc += lam[e] * r;
+        sq += r * r;
+    }
+    acc = wave_sum(acc);
+    sq = wave_sum(sq);
+    if (lane == 0) {
+        a.phi[(size_t)kk * a.B + b] = acc + real(0.5) * rho * sq;
+        if (a.rnorm2) a.rnorm2[(size_t)kk * a.B + b] = sq;
+    }
+}
+
+// line-search decision + update (al_utils.py:634-641), block = instance
+template <typename real>
+__global__ __launch_bounds__(64) void k_pick(AuxArgs<real> a) {
+    const int lane = threadIdx.x, b = blockIdx.x;
+    const int Tn = a.T * (a.nx + a.nu);
+    int kbest = 0;
+    real best = a.phi_all[b];
+    for (int k = 1; k < a.n_ls; ++k) {
+        real v = a.phi_all[(size_t)k * a.B + b];
+        if (!(best != best) && (v != v || v < best)) { best = v; kbest = k; }
+    }
+    const real prev = a.phi_prev[b];
+    const bool acc = best < prev;
+    const real alpha = acc ? real(1) / real(1 << kbest) : real(0);
+    real *z = a.z + (size_t)b * Tn;
+    const real *d = a.d + (size_t)b * Tn;
+    if (acc)
+        for (int e = lane; e < Tn; e += 64) z[e] += alpha * d[e];
+    __syncthreads();
+    if (lane == 0) {
+        a.phi_prev[b] = best;
+        if (a.k_out) a.k_out[b] = kbest;
+        if (a.accept_out) a.accept_out[b] = acc ? 1 : 0;
+    }
+}
+
+// dual update + projection + rho growth (AL_mpc.py:315-317,325), block = instance
+template <typename real>
+__global__ __launch_bounds__(64) void k_dual(AuxArgs<real> a) {
+    const int lane = threadIdx.x, b = blockIdx.x;
+    const int T = a.T, nx = a.nx, nu = a.nu, n = nx + nu, neq = T * nx;
+    const real *z = a.zc + (size_t)b * T * n;
+    const real *xn = a.xnext + (size_t)b * (T - 1) * nx;
+    real *lam = a.lam_io + (size_t)b * (neq + 2 * T * nu);
+    const real *ulo = a.ulo + (size_t)b * a.sb_u, *uhi = a.uhi + (size_t)b * a.sb_u;
+    const real rho = a.rho_io[b];
+    for (int e = lane; e < neq; e += 64) {
+        int t = e / nx, i = e - t * nx;
+        real r = (t < T - 1) ? z[(t + 1) * n + i] - xn[t * nx + i] : z[i] - a.x0[(size_t)b * nx + i];
+        lam[e] += rho * r;
+    }
+    for (int e = lane; e < T * nu; e += 64) {
+        int t = e / nu, j = e - t * nu;
+        real u = z[t * n + nx + j];
+        int ru = neq + t * 2 * nu + j, rl = ru + nu;
+        real v1 = lam[ru] + rho * (u - uhi[t * a.st_u + j]);
+        real v2 = lam[rl] + rho * (-u + ulo[t * a.st_u + j]);
+        lam[ru] = v1 < 0 ? real(0) : v1;
+        lam[rl] = v2 < 0 ? real(0) : v2;
+    }
+    __syncthreads();
+    if (lane == 0) a.rho_io[b] = rho * a.rho_scale;
+}
+
+// ---- dispatch -------------------------------------------------------------------------
+
+// (nx, nu) instances compiled into the library. Anything else is ALQP_E_UNSUPPORTED:
+// the product path fails loudly rather than falling back to a slow generic route.
+#define ALQP_FOR_EACH_DIMS(X) \
+    X(2, 1) X(4, 1) X(4, 2) X(6, 2) X(8, 2) X(10, 3) X(12, 4) X(13, 4) X(14, 4)
+
+constexpr size_t kMaxLds = 160 * 1024;
+
+enum KernelId { KID_SOLVE, KID_STEP, KID_BACKWARD };
+
+template <typename real, int NX, int NU>
+size_t lds_bytes_for(int T) {
+    using C = Cfg<real, NX, NU>;
+    return (size_t)C::QPW * C::team_words(T) * sizeof(real);
+}
+
+template <typename real, int NX, int NU>
+int launch_one(KernelId kid, const SolveArgs<real> &a, hipStream_t stream) {
+    using C = Cfg<real, NX, NU>;
+    const size_t lds = lds_bytes_for<real, NX, NU>(a.T);
+    if (lds > kMaxLds) return ALQP_E_UNSUPPORTED;
+    const unsigned grid = (unsigned)((a.B + C::QPW - 1) / C::QPW);
+    void (*fn)(SolveArgs<real>) = nullptr;
+    switch (kid) {
+        case KID_SOLVE: fn = k_solve_lin<real, NX, NU>; break;
+        case KID_STEP: fn = k_newton_step<real, NX, NU>; break;
+        case KID_BACKWARD: fn = k_backward<real, NX, NU>; break;
+    }
+    if (lds > 48 * 1024) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(fn),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return ALQP_E_LAUNCH;
+    }
+    hipLaunchKernelGGL(fn, dim3(grid), dim3(64), lds, stream, a);
+    return hipGetLastError() == hipSuccess ? 0 : ALQP_E_LAUNCH;
+}
+
+template <typename real>
+int dispatch(KernelId kid, int nx, int nu, const SolveArgs<real> &a, hipStream_t stream) {
+#define X(NX, NU) \
+    if (nx == NX && nu == NU) return launch_one<real, NX, NU>(kid, a, stream);
+    ALQP_FOR_EACH_DIMS(X)
+#undef X
+    return ALQP_E_UNSUPPORTED;
+}
+
+template <typename real>
+size_t lds_query(int nx, int nu, int T) {
+#define X(NX, NU) \
+    if (nx == NX && nu == NU) return lds_bytes_for<real, NX, NU>(T);
+    ALQP_FOR_EACH_DIMS(X)
+#undef X
+    return 0;
+}
+
+static int qpw_query(int nx, int nu) {
+#define X(NX, NU) \
+    if (nx == NX && nu == NU) return Cfg<float, NX, NU>::QPW;
+    ALQP_FOR_EACH_DIMS(X)
+#undef X
+    return 0;
+}
+
+static bool dims_ok(const AlqpDims *d) { return d && d->B > 0 && d->T >= 2 && d->nx > 0 && d->nu > 0; }
+
+template <typename real>
+int solve_lin_impl(const AlqpDims *dims, const AlqpParams *prm, const void *Qd, const void *q,
+                   const void *F, const void *c, const void *x0, const void *u_lo, const void *u_hi,
+                   long sb_u, long st_u, void *z, void *lam, void *rho, void *phi, void *rnorm2,
+                   int *info, unsigned char *status, void *factor_out, const AlqpTrace *trace,
+                   void *stream) {
+    if (!dims_ok(dims) || !prm || !Qd || !q || !F || !c || !x0 || !u_lo || !u_hi || !z || !lam || !rho || !phi)
+        return ALQP_E_BADARG;
+    if (prm->n_ls < 1 || prm->n_ls > 20 || prm->al_iter < 0 || prm->max_newton < 0) return ALQP_E_BADARG;
+    if ((prm->flags & ALQP_SAVE_FACTOR) && !factor_out) return ALQP_E_BADARG;
+    SolveArgs<real> a = {};
+    a.B = dims->B; a.T = dims->T;
+    a.al_iter = prm->al_iter; a.max_newton = prm->max_newton; a.n_ls = prm->n_ls; a.flags = prm->flags;
+    a.rho_scale = (real)prm->rho_scale;
+    a.Qd = (const real *)Qd; a.q = (const real *)q; a.F = (const real *)F; a.c = (const real *)c;
+    a.x0 = (const real *)x0; a.ulo = (const real *)u_lo; a.uhi = (const real *)u_hi;
+    a.sb_u = sb_u; a.st_u = st_u;
+    a.z = (real *)z; a.lam = (real *)lam; a.rho = (real *)rho; a.phi = (real *)phi;
+    a.rnorm2 = (real *)rnorm2; a.info = info; a.status = status; a.factor = (real *)factor_out;
+    if (trace) {
+        a.tr_g = (real *)trace->g; a.tr_d = (real *)trace->d; a.tr_phi = (real *)trace->phi;
+        a.tr_phi_prev = (real *)trace->phi_prev; a.tr_k = trace->k; a.tr_accept = trace->accept;
+    }
+    return dispatch<real>(KID_SOLVE, dims->nx, dims->nu, a, (hipStream_t)stream);
+}
+
+template <typename real>
+int newton_step_impl(const AlqpDims *dims, const void *z, const void *xnext, const void *F,
+                     const void *x0, const void *lam, const void *rho, const void *Qd, const void *q,
+                     const void *u_lo, const void *u_hi, long sb_u, long st_u, void *d_out,
+                     void *g_out, void *factor_out, int *info, void *stream) {
+    if (!dims_ok(dims) || !z || !xnext || !F || !x0 || !lam || !rho || !Qd || !q || !u_lo || !u_hi || !d_out)
+        return ALQP_E_BADARG;
+    SolveArgs<real> a = {};
+    a.B = dims->B; a.T = dims->T;
+    a.Qd = (const real *)Qd; a.q = (const real *)q; a.F = (const real *)F; a.x0 = (const real *)x0;
+    a.ulo = (const real *)u_lo; a.uhi = (const real *)u_hi; a.sb_u = sb_u; a.st_u = st_u;
+    a.xnext = (const real *)xnext;
+    a.z = (real *)z; a.lam = (real *)lam; a.rho = (real *)rho;
+    a.d_out = (real *)d_out; a.g_out = (real *)g_out; a.factor = (real *)factor_out; a.info = info;
+    return dispatch<real>(KID_STEP, dims->nx, dims->nu, a, (hipStream_t)stream);
+}
+
+template <typename real>
+int backward_impl(const AlqpDims *dims, const void *factor, const void *F, const void *rho,
+                  const void *z_final, const void *gbar, void *q_grad, void *Qd_grad, void *stream) {
+    if (!dims_ok(dims) || !factor || !F || !rho || !z_final || !gbar || !q_grad || !Qd_grad)
+        return ALQP_E_BADARG;
+    SolveArgs<real> a = {};
+    a.B = dims->B; a.T = dims->T;
+    a.F = (const real *)F; a.rho = (real *)rho; a.factor = (real *)factor;
+    a.gbar = (const real *)gbar; a.z_final = (const real *)z_final;
+    a.q_grad = (real *)q_grad; a.Qd_grad = (real *)Qd_grad;
+    return dispatch<real>(KID_BACKWARD, dims->nx, dims->nu, a, (hipStream_t)stream);
+}
+
+template <typename real>
+int merit_impl(const AlqpDims *dims, int K, const void *zc, const void *xnext, const void *x0,
+               const void *lam, const void *rho, const void *Qd, const void *q, const void *u_lo,
+               const void *u_hi, long sb_u, long st_u, void *phi, void *rnorm2, void *stream) {
+    if (!dims_ok(dims) || K < 1 || !zc || !xnext || !x0 || !lam || !rho || !Qd || !q || !u_lo || !u_hi || !phi)
+        return ALQP_E_BADARG;
+    AuxArgs<real> a = {};
+    a.B = dims->B; a.T = dims->T; a.nx = dims->nx; a.nu = dims->nu; a.K = K;
+    a.zc = (const real *)zc; a.xnext = (const real *)xnext; a.x0 = (const real *)x0;
+    a.lam = (const real *)lam; a.rho = (const real *)rho; a.Qd = (const real *)Qd; a.q = (const real *)q;
+    a.ulo = (const real *)u_lo; a.uhi = (const real *)u_hi; a.sb_u = sb_u; a.st_u = st_u;
+    a.phi = (real *)phi; a.rnorm2 = (real *)rnorm2;
+    hipLaunchKernelGGL(k_merit<real>, dim3((unsigned)((size_t)K * dims->B)), dim3(64), 0,
+                       (hipStream_t)stream, a);
+    return hipGetLastError() == hipSuccess ? 0 : ALQP_E_LAUNCH;
+}
+
+template <typename real>
+int pick_impl(const AlqpDims *dims, int n_ls, const void *phi, void *phi_prev, const void *d, void *z,
+              int *k_out, int *accept_out, void *stream) {
+    if (!dims_ok(dims) || n_ls < 1 || !phi || !phi_prev || !d || !z) return ALQP_E_BADARG;
+    AuxArgs<real> a = {};
+    a.B = dims->B; a.T = dims->T; a.nx = dims->nx; a.nu = dims->nu; a.n_ls = n_ls;
+    a.phi_all = (const real *)phi; a.phi_prev = (real *)phi_prev; a.d = (const real *)d; a.z = (real *)z;
+    a.k_out = k_out; a.accept_out = accept_out;
+    hipLaunchKernelGGL(k_pick<real>, dim3(dims->B), dim3(64), 0, (hipStream_t)stream, a);
+    return hipGetLastError() == hipSuccess ? 0 : ALQP_E_LAUNCH;
+}
+
+template <typename real>
+int dual_impl(const AlqpDims *dims, const void *z, const void *xnext, const void *x0, const void *u_lo,
+              const void *u_hi, long sb_u, long st_u, void *lam, void *rho, double rho_scale,
+              void *stream) {
+    if (!dims_ok(dims) || !z || !xnext || !x0 || !u_lo || !u_hi || !lam || !rho) return ALQP_E_BADARG;
+    AuxArgs<real> a = {};
+    a.B = dims->B; a.T = dims->T; a.nx = dims->nx; a.nu = dims->nu;
+    a.zc = (const real *)z; a.xnext = (const real *)xnext; a.x0 = (const real *)x0;
+    a.ulo = (const real *)u_lo; a.uhi = (const real *)u_hi; a.sb_u = sb_u; a.st_u = st_u;
+    a.lam_io = (real *)lam; a.rho_io = (real *)rho; a.rho_scale = (real)rho_scale;
+    hipLaunchKernelGGL(k_dual<real>, dim3(dims->B), dim3(64), 0, (hipStream_t)stream, a);
+    return hipGetLastError() == hipSuccess ? 0 : ALQP_E_LAUNCH;
+}
+
+}  // namespace alqp
+
+// ---- C ABI -------------------------------------------------------------------------------
+extern "C" {
+
+int alqp_abi_version(void) { return 1; }
+
+size_t alqp_lds_bytes(const AlqpDims *dims, int is_f64) {
+    if (!alqp::dims_ok(dims)) return 0;
+    size_t v = is_f64 ? alqp::lds_query<double>(dims->nx, dims->nu, dims->T)
+                      : alqp::lds_query<float>(dims->nx, dims->nu, dims->T);
+    return v;
+}
+
+int alqp_supported(const AlqpDims *dims, int is_f64) {
+    size_t v = alqp_lds_bytes(dims, is_f64);
+    return v > 0 && v <= alqp::kMaxLds;
+}
+
+int alqp_qps_per_wave(const AlqpDims *dims, int is_f64) {
+    (void)is_f64;
+    if (!alqp::dims_ok(dims)) return 0;
+    return alqp::qpw_query(dims->nx, dims->nu);
+}
+
+#define ALQP_DEFINE(SFX, REAL)                                                                        \
+    int alqp_solve_lin_##SFX(const AlqpDims *dims, const AlqpParams *prm, const void *Qd,             \
+                             const void *q, const void *F, const void *c, const void *x0,             \
+                             const void *u_lo, const void *u_hi, long sb_u, long st_u, void *z,       \
+                             void *lam, void *rho, void *phi, void *rnorm2, int *info,                \
+                             unsigned char *status, void *factor_out, const AlqpTrace *trace,         \
+                             void *stream) {                                                          \
+        return alqp::solve_lin_impl<REAL>(dims, prm, Qd, q, F, c, x0, u_lo, u_hi, sb_u, st_u, z, lam, \
+                                          rho, phi, rnorm2, info, status, factor_out, trace, stream); \
+    }                                                                                                 \
+    int alqp_newton_step_##SFX(const AlqpDims *dims, const void *z, const void *xnext, const void *F, \
+                               const void *x0, const void *lam, const void *rho, const void *Qd,      \
+                               const void *q, const void *u_lo, const void *u_hi, long sb_u,          \
+                               long st_u, void *d_out, void *g_out, void *factor_out, int *info,      \
+                               void *stream) {                                                        \
+        return alqp::newton_step_impl<REAL>(dims, z, xnext, F, x0, lam, rho, Qd, q, u_lo, u_hi, sb_u, \
+                                            st_u, d_out, g_out, factor_out, info, stream);            \
+    }                                                                                                 \
+    int alqp_merit_##SFX(const AlqpDims *dims, int K, const void *zc, const void *xnext,              \
+                         const void *x0, const void *lam, const void *rho, const void *Qd,            \
+                         const void *q, const void *u_lo, const void *u_hi, long sb_u, long st_u,     \
+                         void *phi, void *rnorm2, void *stream) {                                     \
+        return alqp::merit_impl<REAL>(dims, K, zc, xnext, x0, lam, rho, Qd, q, u_lo, u_hi, sb_u,      \
+                                      st_u, phi, rnorm2, stream);                                     \
+    }                                                                                                 \
+    int alqp_linesearch_pick_##SFX(const AlqpDims *dims, int n_ls, const void *phi, void *phi_prev,   \
+                                   const void *d, void *z, int *k_out, int *accept_out,               \
+                                   void *stream) {                                                    \
+        return alqp::pick_impl<REAL>(dims, n_ls, phi, phi_prev, d, z, k_out, accept_out, stream);     \
+    }                                                                                                 \
+    int alqp_dual_update_##SFX(const AlqpDims *dims, const void *z, const void *xnext,                \
+                               const void *x0, const void *u_lo, const void *u_hi, long sb_u,         \
+                               long st_u, void *lam, void *rho, double rho_scale, void *stream) {     \
+        return alqp::dual_impl<REAL>(dims, z, xnext, x0, u_lo, u_hi, sb_u, st_u, lam, rho, rho_scale, \
+                                     stream);                                                         \
+    }                                                                                                 \
+    int alqp_backward_##SFX(const AlqpDims *dims, const void *factor, const void *F, const void *rho, \
+                            const void *z_final, const void *gbar, void *q_grad, void *Qd_grad,       \
+                            void *stream) {                                                           \
+        return alqp::backward_impl<REAL>(dims, factor, F, rho, z_final, gbar, q_grad, Qd_grad,        \
+                                         stream);                                                     \
+    }
+
+ALQP_DEFINE(f32, float)
+ALQP_DEFINE(f64, double)
+
+}  // extern "C"

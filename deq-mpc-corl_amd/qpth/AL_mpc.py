@@ -1,0 +1,502 @@
+"""Drop-in for the reference's ``qpth.AL_mpc`` module, MI355X-native.
+
+``MPC`` keeps the surface the DEQ-MPC loop touches (callers are
+``deqmpc/policies.py:1181-1216, 1236-1315`` of the reference):
+
+  * ctor ``MPC(n_state, n_ctrl, T, u_lower, u_upper, ..., n_batch, dtype)``
+    (qpth/AL_mpc.py:118-142; the kwargs the reference ignores are accepted and
+    ignored here too),
+  * ``__call__(x0, cost, dx, dx_jac, compute_Qq=None, u_init=None, x_init=None)
+    -> (x[B,T,nx] f32, u[B,T,nu] f32, status)`` (qpth/AL_mpc.py:207-258),
+  * ``reinitialize(x, mask)`` (must precede the first call, :569-579),
+    ``warm_start_initialize(x, u, args)`` (:581-592),
+  * attributes ``al_iter, x_init, u_init, lamda_prev, rho_prev`` and
+    ``get_xu() / get_cost()`` (:560-567).
+
+What runs where: this file is host logic only (state carry, dispatch, the
+batch-global exit test that needs a host decision). All arithmetic of the AL
+inner iteration - gradient, block-tridiagonal Cholesky, Newton step, 20-point
+line search, dual update - is in the HIP kernels behind ``backend`` (csrc/).
+There is no CPU path: without the built extension and a ROCm device it raises.
+
+Two exit modes for the Newton loop:
+  ``"reference"``  reproduces the reference's batch-global early exit
+                   (al_utils.py:486,552,560-564): one kernel launch per Newton
+                   step and a host read of sum_b |r+|^2 in between, exactly the
+                   host syncs the reference has (its ``.item()`` calls);
+  ``"fixed"``      always 4 Newton steps per AL iteration: the whole solve is one
+                   kernel launch, no host sync, results do not depend on who else
+                   is in the batch (so sharding the batch changes nothing).
+"""
+from __future__ import annotations
+
+import math
+import os
+import sys
+
+import torch
+from torch.nn import Module
+
+try:  # the package may be reached as top-level `qpth` (drop-in) or via the alias
+    import deq_mpc_corl_amd  # noqa: F401
+except ImportError:  # pragma: no cover
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+    import deq_mpc_corl_amd  # noqa: F401
+
+from deq_mpc_corl_amd import _lib as _abi
+from deq_mpc_corl_amd.qpth import al_utils
+from deq_mpc_corl_amd.qpth.al_utils import LinDx, QuadCost  # noqa: F401  (re-exported)
+
+MAX_NEWTON = 4   # al_utils.py:485
+N_LS = 20        # al_utils.py:619
+RHO_SCALE = 10.0  # AL_mpc.py:325
+
+
+def _detach_maybe(t):
+    if t is None:
+        return None
+    return t.detach() if t.requires_grad else t
+
+
+class _SolveState:
+    """Everything the solve needs that autograd must not see."""
+
+    __slots__ = ("mpc", "x0", "z", "lam", "rho", "dx", "dx_jac", "lin", "stream_mode",
+                 "status_flag", "per_instance_status", "newton_per_al")
+
+
+class _ALSolve(torch.autograd.Function):
+    """The whole AL solve as one differentiable node.
+
+    Like the reference, only the LAST AL iteration is differentiated (earlier ones
+    are cut by ``.detach().clone()``, AL_mpc.py:299) and only w.r.t. q and diag(Q)
+    (NewtonAL.backward, al_utils.py:578-615): w = -H^{-1} gbar with the factor saved
+    at the last executed Newton step, q_grad = w, Q_grad = w * z_final.
+    """
+
+    @staticmethod
+    def forward(ctx, Qd, q, st):
+        mpc = st.mpc
+        need_grad = Qd.requires_grad or q.requires_grad
+        with torch.no_grad():
+            saved = mpc._run(st, Qd.detach().contiguous(), q.detach().contiguous(), need_grad)
+        ctx.mpc = mpc
+        ctx.has_factor = saved is not None
+        if saved is not None:
+            factor, F_last, rho_last = saved
+            ctx.save_for_backward(factor, F_last, rho_last, st.z)
+        ctx.dims = (st.z.shape[0], mpc.T, mpc.n_state, mpc.n_ctrl)
+        return st.z.clone()
+
+    @staticmethod
+    def backward(ctx, gz):
+        if not ctx.has_factor:
+            return None, None, None
+        factor, F_last, rho_last, z_final = ctx.saved_tensors
+        gbar = gz.to(z_final.dtype).contiguous()
+        q_grad = torch.empty_like(z_final)
+        Qd_grad = torch.empty_like(z_final)
+        ctx.mpc.backend.backward(ctx.dims, factor, F_last, rho_last, z_final, gbar, q_grad, Qd_grad)
+        return Qd_grad, q_grad, None
+
+
+class MPC(Module):
+    """Batched box-constrained MPC solved by an augmented-Lagrangian method
+    (same problem statement as qpth/AL_mpc.py:53-63):
+
+        min_{x,u} sum_t 1/2 tau_t' C_t tau_t + c_t' tau_t     tau_t = [x_t; u_t]
+        s.t.      x_{t+1} = f(x_t, u_t),  x_0 = x_init,  u_lower <= u <= u_upper
+    """
+
+    def __init__(self, n_state, n_ctrl, T, u_lower=None, u_upper=None, u_init=None, x_init=None,
+                 al_iter=2, verbose=0, eps=1e-7, back_eps=1e-7, n_batch=None,
+                 linesearch_decay=0.2, max_linesearch_iter=10, exit_unconverged=True,
+                 detach_unconverged=True, backprop=True, slew_rate_penalty=None,
+                 solver_type="dense", add_goal_constraint=False, x_goal=None, diag_cost=True,
+                 ineqG=None, ineqh=None, state_estimator=False, dtype=torch.float64,
+                 exit_mode="reference", backend=None, process_group=None):
+        super().__init__()
+        if (u_lower is None) != (u_upper is None) or u_lower is None:
+            raise ValueError("MPC: u_lower and u_upper are both required (AL_mpc.py:145,152)")
+        if state_estimator:
+            raise NotImplementedError("state_estimator=True (al_utils_se) is outside the hot path")
+        if add_goal_constraint or ineqG is not None or not diag_cost:
+            raise NotImplementedError("goal constraints / general inequalities / dense cost are "
+                                      "not reachable from Tracking_MPC and are not built")
+        if exit_mode not in ("reference", "fixed"):
+            raise ValueError("exit_mode must be 'reference' or 'fixed'")
+        self.dtype = dtype
+        self.n_state, self.n_ctrl, self.T = n_state, n_ctrl, T
+        self.u_lower = _detach_maybe(torch.as_tensor(u_lower).to(dtype))
+        self.u_upper = _detach_maybe(torch.as_tensor(u_upper).to(dtype))
+        self.u_init = _detach_maybe(u_init)
+        self.x_init = _detach_maybe(x_init)
+        self.al_iter = al_iter
+        self.verbose = verbose
+        self.n_batch = n_batch
+        self.diag_cost = True
+        self.linearize_once = False
+        self.recompute_Qq = False
+        self.state_estimator = False
+        self.neq = n_state * T
+        self.nineq = 2 * n_ctrl * T
+        self.rho_prev = 1.0
+        self.rho_max = 1e8
+        self.dyn_res_prev = 1000000
+        self.exit_mode = exit_mode
+        self.process_group = process_group
+        self._backend = backend
+        self.warm_starting = None  # set by reinitialize(); forward() insists on it
+        self.cost_hist_stream = [[], []]
+        self.lamda_prev = None
+        if n_batch is not None:
+            self.lamda_prev = torch.zeros(n_batch, self.neq + self.nineq, dtype=dtype,
+                                          device=self.u_upper.device)
+        self.mask = None
+        self.last_status = None
+        self.last_info = None
+        self.last_newton_per_al = None
+
+    # -- backend -----------------------------------------------------------------
+    @property
+    def backend(self):
+        if self._backend is None:
+            from deq_mpc_corl_amd.backend import default_backend
+            self._backend = default_backend()
+        return self._backend
+
+    # -- reference surface ---------------------------------------------------------
+    def reinitialize(self, x, mask):
+        """rho <- 1, lam <- 0, warm starts dropped (AL_mpc.py:569-579)."""
+        self.u_init = None
+        self.x_init = None
+        self.n_batch = x.size(0)
+        self.rho_prev = torch.ones((self.n_batch, 1), device=x.device, dtype=x.dtype)
+        self.lamda_prev = torch.zeros(self.n_batch, self.neq + self.nineq, device=x.device, dtype=x.dtype)
+        self.cost_hist_stream = [[], []]
+        self.dyn_res_prev = 1000000
+        self.just_initialized = True
+        self.warm_starting = False
+        self.mask = mask
+
+    def warm_start_initialize(self, x, u, args):
+        """Streaming warm start (AL_mpc.py:581-592): inits <- given, multipliers are
+        shifted one stage and then zeroed (the reference multiplies by 0, :589),
+        rho <- min(rho, args.rho_init_max)."""
+        self.u_init = u
+        self.x_init = x
+        self.lamda_prev = torch.zeros_like(self.lamda_prev)
+        self.rho_prev = torch.clamp(self.rho_prev, max=args.rho_init_max)
+        self.just_initialized = True
+        self.warm_starting = True
+
+    def get_xu(self):
+        return torch.cat((self.x_init, self.u_init), dim=2)
+
+    def get_cost(self, cost):
+        xu = self.get_xu()
+        Qd = cost.C.diagonal(dim1=-2, dim2=-1)
+        f = cost.f.sum(dim=-1) if cost.f is not None else 0.0
+        return (0.5 * (xu * Qd * xu).sum(-1) + (cost.c * xu).sum(-1)).sum(dim=-1) + f
+
+    def rollout(self, x, actions, dynamics):
+        """x_{t+1} = f(x_t, u_t) from x_0 (AL_mpc.py:521-534)."""
+        xs = [x]
+        lin = self._as_lindx(dynamics, x.shape[0])
+        for t in range(self.T - 1):
+            xt, ut = xs[t], actions[:, t]
+            if lin is not None:
+                F, c = lin
+                nxt = torch.einsum("bij,bj->bi", F[:, t].to(xt.dtype), torch.cat([xt, ut], -1)) + c[:, t].to(xt.dtype)
+            else:
+                nxt = dynamics(xt, ut)
+            xs.append(nxt)
+        return torch.stack(xs, 1)
+
+    def forward(self, x0, cost, dx, dx_jac, compute_Qq=None, u_init=None, x_init=None):
+        if self.warm_starting is None:
+            raise RuntimeError("MPC.reinitialize(x, mask) must be called before the first solve "
+                               "(the reference creates `warm_starting` there, AL_mpc.py:578)")
+        self.compute_Qq = compute_Qq
+        B = self.n_batch if self.n_batch is not None else cost.C.size(0)
+        assert cost.C.ndimension() == 4
+        assert x0.ndimension() == 2 and x0.size(0) == B
+
+        def expand(v):
+            return v.unsqueeze(0).expand(B, self.T, -1).clone() if v.ndimension() == 2 else v
+
+        if u_init is not None:
+            u = expand(u_init)
+        elif self.u_init is None:
+            u = torch.zeros(B, self.T, self.n_ctrl, dtype=x0.dtype, device=x0.device)
+        else:
+            u = expand(self.u_init)
+        u = u.type_as(x0.data)
+        if x_init is not None:
+            x = expand(x_init)
+        elif self.x_init is None:
+            x = self.rollout(x0, u, dx)
+        else:
+            x = expand(self.x_init)
+        x = x.type_as(x0.data)
+
+        Qd = cost.C.diagonal(dim1=-2, dim2=-1)
+        x, u, status = self._al_solve(x, u, dx, dx_jac, x0, Qd, cost.c, bool(self.warm_starting))
+        self.x_init = x.detach().clone()
+        self.u_init = u.detach().clone()
+        return x, u, status
+
+    # the reference exposes both names; both end in the same machinery here
+    def al_solve(self, x, u, dx, dx_jac, x0, cost, lamda_init=None, rho_init=None):
+        if lamda_init is not None:
+            self.lamda_prev = lamda_init
+        if rho_init is not None:
+            self.rho_prev = rho_init
+        return self._al_solve(x, u, dx, dx_jac, x0, cost.C, cost.c, False)
+
+    def al_solve_stream(self, x, u, dx, dx_jac, x0, cost, lamda_init=None, rho_init=None):
+        if lamda_init is not None:
+            self.lamda_prev = lamda_init
+        if rho_init is not None:
+            self.rho_prev = rho_init
+        return self._al_solve(x, u, dx, dx_jac, x0, cost.C, cost.c, True)
+
+    # -- internals -------------------------------------------------------------------
+    def _as_lindx(self, dx, B):
+        """(F[B,T-1,nx,n], c[B,T-1,nx]) if `dx` carries affine data, else None."""
+        F = getattr(dx, "F", None)
+        c = getattr(dx, "f", None)
+        if F is None or c is None or not torch.is_tensor(F):
+            return None
+        n = self.n_state + self.n_ctrl
+        if tuple(F.shape) != (B, self.T - 1, self.n_state, n):
+            raise ValueError(f"LinDx.F must be [B,T-1,nx,n]={B, self.T - 1, self.n_state, n}, got {tuple(F.shape)}")
+        return F, c
+
+    def _bounds(self, B, dtype, device):
+        lo = self.u_lower.to(device=device, dtype=dtype)
+        hi = self.u_upper.to(device=device, dtype=dtype)
+        nu = self.n_ctrl
+        if lo.dim() <= 1 and hi.dim() <= 1:
+            lo = lo.reshape(-1).expand(nu).contiguous()
+            hi = hi.reshape(-1).expand(nu).contiguous()
+            return lo, hi, 0, 0
+        lo = lo.expand(B, self.T, nu).contiguous()
+        hi = hi.expand(B, self.T, nu).contiguous()
+        return lo, hi, self.T * nu, nu
+
+    def _rho_tensor(self, B, dtype, device):
+        r = self.rho_prev
+        if not torch.is_tensor(r):
+            return torch.full((B,), float(r), dtype=dtype, device=device)
+        return r.to(device=device, dtype=dtype).reshape(B).contiguous().clone()
+
+    def _global_norm(self, rn2):
+        """sqrt(sum_b sum_rows r+^2): the batch-global quantity the reference exits on
+        (torch.norm(dyn_res).item(), al_utils.py:486,552). With a sharded batch the
+        partial sums are all-reduced (8 bytes over RCCL) so that every rank takes the
+        same decision the un-sharded reference would."""
+        s = rn2.sum(dtype=torch.float64)
+        if self.process_group is not None or (
+                torch.distributed.is_available() and torch.distributed.is_initialized()
+                and getattr(self, "sync_global_exit", False)):
+            torch.distributed.all_reduce(s, group=self.process_group)
+        return math.sqrt(float(s.item()))
+
+    def _al_solve(self, x, u, dx, dx_jac, x0, Qd, q, stream_mode):
+        B = x.shape[0]
+        dt = self.dtype
+        dev = x0.device
+        if self.lamda_prev is None:
+            self.lamda_prev = torch.zeros(B, self.neq + self.nineq, dtype=dt, device=dev)
+        st = _SolveState()
+        st.mpc = self
+        st.x0 = x0.detach().to(dt).contiguous()
+        st.z = torch.cat((x, u), dim=2).detach().to(dt).contiguous().clone()
+        st.lam = self.lamda_prev.detach().to(device=dev, dtype=dt).contiguous().clone()
+        st.rho = self._rho_tensor(B, dt, dev)
+        st.dx, st.dx_jac = dx, dx_jac
+        st.lin = self._as_lindx(dx, B)
+        st.stream_mode = stream_mode
+        st.status_flag = False
+        z = _ALSolve.apply(Qd.to(dt), q.to(dt), st)
+        self.lamda_prev = st.lam
+        self.rho_prev = st.rho.reshape(B, 1)
+        self.just_initialized = False
+        self.last_newton_per_al = st.newton_per_al
+        nx = self.n_state
+        return z[..., :nx].float(), z[..., nx:].float(), st.status_flag
+
+    # one NewtonAL.forward worth of work on affine data, host-driven exit
+    def _newton_al_lin(self, st, Qd, q, F, c, bnd, ws, need_factor):
+        be = self.backend
+        dims = (st.z.shape[0], self.T, self.n_state, self.n_ctrl)
+        lo, hi, sb, stt = bnd
+        common = dict(rnorm2=ws["rn2"], info=ws["info"], status=ws["status"], n_ls=N_LS,
+                      rho_scale=RHO_SCALE)
+        fl_save = _abi.ALQP_SAVE_FACTOR if need_factor else 0
+        if self.exit_mode == "fixed":
+            be.solve_lin(dims, Qd, q, F, c, st.x0, lo, hi, sb, stt, st.z, st.lam, st.rho, ws["phi"],
+                         factor=ws.get("factor"), al_iter=1, max_newton=MAX_NEWTON,
+                         flags=_abi.ALQP_INIT_MERIT | fl_save, **common)
+            return MAX_NEWTON
+        be.solve_lin(dims, Qd, q, F, c, st.x0, lo, hi, sb, stt, st.z, st.lam, st.rho, ws["phi"],
+                     al_iter=1, max_newton=0, flags=_abi.ALQP_INIT_MERIT, **common)
+        old = self._global_norm(ws["rn2"])
+        n = 0
+        while n < MAX_NEWTON:
+            n += 1
+            be.solve_lin(dims, Qd, q, F, c, st.x0, lo, hi, sb, stt, st.z, st.lam, st.rho, ws["phi"],
+                         factor=ws.get("factor"), al_iter=1, max_newton=1, flags=fl_save, **common)
+            new = self._global_norm(ws["rn2"])
+            if new < 1e-3 or abs(old - new) / new < 1e-3:
+                break
+            old = new
+        return n
+
+    def _newton_al_nonlin(self, st, Qd, q, bnd, ws, need_factor):
+        """NewtonAL.forward (al_utils.py:451-576) with `dx`/`dx_jac` as PyTorch calls
+        between kernel launches."""
+        be = self.backend
+        B, T, nx, nu = st.z.shape[0], self.T, self.n_state, self.n_ctrl
+        n = nx + nu
+        dims = (B, T, nx, nu)
+        lo, hi, sb, stt = bnd
+        z = st.z
+        dt = z.dtype
+
+        def dyn(zz):  # zz [..., T, n] -> f(x_t,u_t) [..., T-1, nx]
+            lead = zz.shape[:-2]
+            xn = st.dx(zz[..., :-1, :nx].reshape(-1, nx), zz[..., :-1, nx:].reshape(-1, nu))
+            return xn.reshape(*lead, T - 1, nx).to(dt).contiguous()
+
+        xn = dyn(z)
+        be.merit(dims, 1, z, xn, st.x0, st.lam, st.rho, Qd, q, lo, hi, sb, stt, ws["phi"], ws["rn2"])
+        old = self._global_norm(ws["rn2"]) if self.exit_mode == "reference" else None
+        alphas = (2.0 ** -torch.arange(N_LS, device=z.device, dtype=dt)).view(N_LS, 1, 1, 1)
+        steps = 0
+        while steps < MAX_NEWTON:
+            steps += 1
+            xn_j, (A, Bm) = st.dx_jac(z[:, :-1, :nx].reshape(-1, nx), z[:, :-1, nx:].reshape(-1, nu))
+            F = torch.cat((A.reshape(B, T - 1, nx, nx), Bm.reshape(B, T - 1, nx, nu)), dim=-1).to(dt).contiguous()
+            xn = xn_j.reshape(B, T - 1, nx).to(dt).contiguous()
+            be.newton_step(dims, z, xn, F, st.x0, st.lam, st.rho, Qd, q, lo, hi, sb, stt, ws["d"],
+                           factor=ws.get("factor") if need_factor else None, info=ws["info"])
+            if need_factor:
+                ws["F_last"] = F
+            zc = (z.unsqueeze(0) + alphas * ws["d"].unsqueeze(0)).contiguous()
+            xnc = dyn(zc)
+            be.merit(dims, N_LS, zc, xnc, st.x0, st.lam, st.rho, Qd, q, lo, hi, sb, stt,
+                     ws["phis"], ws["rn2s"])
+            be.linesearch_pick(dims, N_LS, ws["phis"], ws["phi"], ws["d"], z, ws["k"], ws["acc"])
+            if self.exit_mode == "reference":
+                rn2 = torch.where(ws["acc"].bool(), ws["rn2s"].gather(0, ws["k"].long().unsqueeze(0)).squeeze(0),
+                                  ws["rn2"])
+                ws["rn2"].copy_(rn2)
+                new = self._global_norm(ws["rn2"])
+                if new < 1e-3 or abs(old - new) / new < 1e-3:
+                    break
+                old = new
+        return steps
+
+    def _run(self, st, Qd, q, need_grad):
+        """The AL outer loop (AL_mpc.py:260-339 / :342-423). Mutates st.z/lam/rho.
+        Returns (factor, F_last, rho_last) when a backward pass may follow."""
+        be = self.backend
+        B, T, nx, nu = st.z.shape[0], self.T, self.n_state, self.n_ctrl
+        n = nx + nu
+        dt, dev = st.z.dtype, st.z.device
+        dims = (B, T, nx, nu)
+        if not be.supported(B, T, nx, nu, dt):
+            raise RuntimeError(f"mi_alqp: no kernel instance for (nx={nx}, nu={nu}, T={T}, {dt}); "
+                               "add it to ALQP_FOR_EACH_DIMS in csrc/alqp_kernels.hip")
+        bnd = self._bounds(B, dt, dev)
+        lo, hi, sb, stt = bnd
+        ws = {"phi": torch.zeros(B, dtype=dt, device=dev), "rn2": torch.zeros(B, dtype=dt, device=dev),
+              "info": torch.zeros(B, dtype=torch.int32, device=dev),
+              "status": torch.ones(B, dtype=torch.uint8, device=dev)}
+        if need_grad:
+            ws["factor"] = torch.empty(B, T, n * (n + 1) // 2, dtype=dt, device=dev)
+        lin = st.lin
+        stream = st.stream_mode
+        linearize_once = bool(self.linearize_once) and stream
+        npa = []
+        rho_last = None
+        F_last = None
+
+        if lin is None or linearize_once:
+            ws.update(d=torch.empty(B, T, n, dtype=dt, device=dev),
+                      phis=torch.empty(N_LS, B, dtype=dt, device=dev),
+                      rn2s=torch.empty(N_LS, B, dtype=dt, device=dev),
+                      k=torch.zeros(B, dtype=torch.int32, device=dev),
+                      acc=torch.zeros(B, dtype=torch.int32, device=dev))
+
+        def true_next(z):
+            xn = st.dx(z[:, :-1, :nx].reshape(-1, nx), z[:, :-1, nx:].reshape(-1, nu))
+            return xn.reshape(B, T - 1, nx).to(dt).contiguous()
+
+        F = c = None
+        if lin is not None and not linearize_once:
+            F = lin[0].detach().to(device=dev, dtype=dt).contiguous()
+            c = lin[1].detach().to(device=dev, dtype=dt).contiguous()
+        elif linearize_once:
+            # frozen linearisation captured once per call (al_utils_lin.py:140-169)
+            z = st.z
+            _, (A, Bm) = st.dx_jac(z[:, :-1, :nx].reshape(-1, nx), z[:, :-1, nx:].reshape(-1, nu))
+            F = torch.cat((A.reshape(B, T - 1, nx, nx), Bm.reshape(B, T - 1, nx, nu)), dim=-1).to(dt).contiguous()
+            c = (z[:, 1:, :nx] - torch.einsum("btij,btj->bti", F, z[:, :-1])).contiguous()
+
+        # ---- fast path: the whole solve in ONE launch -----------------------------------
+        if F is not None and not stream and self.exit_mode == "fixed":
+            flags = _abi.ALQP_INIT_MERIT | _abi.ALQP_DUAL_UPDATE | (_abi.ALQP_SAVE_FACTOR if need_grad else 0)
+            be.solve_lin(dims, Qd, q, F, c, st.x0, lo, hi, sb, stt, st.z, st.lam, st.rho, ws["phi"],
+                         rnorm2=ws["rn2"], info=ws["info"], status=ws["status"],
+                         factor=ws.get("factor"), al_iter=self.al_iter, max_newton=MAX_NEWTON,
+                         n_ls=N_LS, flags=flags, rho_scale=RHO_SCALE)
+            npa = [MAX_NEWTON] * self.al_iter
+            rho_last = st.rho / RHO_SCALE
+            F_last = F
+        else:
+            num_iters = 100 if linearize_once else self.al_iter
+            prev_mean = None
+            if linearize_once:  # dyn_res_clamp_prev starts at the residual of the warm start (:358-369)
+                xn = true_next(st.z)
+                be.merit(dims, 1, st.z, xn, st.x0, st.lam, st.rho, Qd, q, lo, hi, sb, stt,
+                         ws["phi"], ws["rn2"])
+                prev_mean = float(ws["rn2"].sqrt().mean().item())
+            for _ in range(num_iters):
+                rho_last = st.rho.clone()
+                if F is not None:
+                    npa.append(self._newton_al_lin(st, Qd, q, F, c, bnd, ws, need_grad))
+                    F_last = F
+                else:
+                    npa.append(self._newton_al_nonlin(st, Qd, q, bnd, ws, need_grad))
+                    F_last = ws.get("F_last")
+                # dual update with the TRUE dynamics (AL_mpc.py:315-317 / :397-399)
+                if F is not None and not linearize_once:
+                    be.solve_lin(dims, Qd, q, F, c, st.x0, lo, hi, sb, stt, st.z, st.lam, st.rho,
+                                 ws["phi"], rnorm2=ws["rn2"], info=None, status=ws["status"],
+                                 al_iter=1, max_newton=0, n_ls=N_LS, flags=_abi.ALQP_DUAL_UPDATE,
+                                 rho_scale=RHO_SCALE)
+                else:
+                    xn = true_next(st.z)
+                    be.merit(dims, 1, st.z, xn, st.x0, st.lam, st.rho, Qd, q, lo, hi, sb, stt,
+                             ws["phi"], ws["rn2"])
+                    be.dual_update(dims, st.z, xn, st.x0, lo, hi, sb, stt, st.lam, st.rho, RHO_SCALE)
+                if stream:
+                    if linearize_once:
+                        mean = float(ws["rn2"].sqrt().mean().item())
+                        if prev_mean is not None and not mean < prev_mean:
+                            break
+                        prev_mean = mean
+                    if float(st.rho.max().item()) > self.rho_max:
+                        break
+            if stream and float(st.rho.max().item()) > self.rho_max:
+                st.status_flag = True
+        st.newton_per_al = npa
+        self.last_status = ws["status"].bool()
+        self.last_info = ws["info"]
+        self.dyn_res_prev = ws["rn2"].sqrt()
+        if need_grad and F_last is not None:
+            return ws["factor"], F_last, rho_last
+        return None

@@ -1,0 +1,173 @@
+/*
+ * mi_alqp.h - C ABI of the MI355X-native batched augmented-Lagrangian MPC/QP solver.
+ *
+ * The reference (anonymous-author-918/deq-mpc-corl) has no native interface for this
+ * path: its AL solver is eager PyTorch (qpth/AL_mpc.py, qpth/al_utils.py). The entry
+ * points below are what a binding for that path would call; each one names the
+ * reference code it replaces. INTEGRATION.md shows the ctypes stub.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer owned by the caller (e.g. PyTorch's caching
+ *     allocator); the library never allocates, frees or synchronises;
+ *   - work is enqueued on `stream` (a hipStream_t passed as void*), so ordering is
+ *     stream order; every call is re-entrant (no global state);
+ *   - return value: 0 on success, <0 on bad arguments / unsupported dims / launch
+ *     failure (ALQP_E_*). Numerical trouble is reported per instance in info[] / status[];
+ *   - dtype suffix _f32 / _f64 is the arithmetic AND storage type of all real arrays;
+ *   - batch-first row-major layouts, as the reference uses them:
+ *       z   [B][T][n]        n = nx+nu, state first        (xu in al_utils.py)
+ *       Qd,q[B][T][n]        diagonal of QuadCost.C and QuadCost.c (AL_mpc.py:250)
+ *       F   [B][T-1][nx][n]  [A_t B_t]  (dynamics Jacobian, al_utils.py:242-248)
+ *       c   [B][T-1][nx]     affine offset of LinDx-style dynamics
+ *       xnext[B][T-1][nx]    f(x_t,u_t) evaluated by the caller (nonlinear mode)
+ *       x0  [B][nx]
+ *       lam [B][M]           M = T*nx + 2*T*nu; eq rows t*nx+i (t<T-1 dynamics, t=T-1 the
+ *                            initial-state row), then ineq rows T*nx + t*2nu + j
+ *                            (j<nu upper, j>=nu lower)  (al_utils.py:218-225, 293)
+ *       rho [B]              (the reference's [B,1])
+ *       u_lo,u_hi            element (b,t,j) at b*sb_u + t*st_u + j  (0 strides broadcast)
+ *       factor[B][T][n(n+1)/2]  packed rows of X_t = L_tt^{-T} of the block-tridiagonal
+ *                            Cholesky factor (row i holds X[i][i..n-1])
+ */
+#ifndef MI_ALQP_H
+#define MI_ALQP_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct AlqpDims {
+    int B;   /* instances */
+    int T;   /* horizon, >= 2 */
+    int nx;  /* state dim */
+    int nu;  /* control dim */
+} AlqpDims;
+
+/* flags for alqp_solve_lin_* */
+#define ALQP_INIT_MERIT   1  /* evaluate merit(z) at the start of every AL iteration (al_utils.py:481) */
+#define ALQP_DUAL_UPDATE  2  /* lam += rho*r, clamp, rho *= rho_scale after the Newton steps (AL_mpc.py:315-325) */
+#define ALQP_SAVE_FACTOR  4  /* write the factor of the last executed Newton step to factor_out */
+
+typedef struct AlqpParams {
+    int al_iter;      /* AL outer iterations done by this call (AL_mpc.py:290) */
+    int max_newton;   /* Newton steps per AL iteration, reference: 4 (al_utils.py:485) */
+    int n_ls;         /* line-search candidates 2^-k, reference: 20 (al_utils.py:619); <= 20 */
+    int flags;        /* ALQP_* */
+    double rho_scale; /* reference: 10 (AL_mpc.py:325) */
+} AlqpParams;
+
+/* optional per-step trace (all nullable, for tests): S = al_iter*max_newton steps */
+typedef struct AlqpTrace {
+    void *g;        /* [S][B][T][n] merit gradient */
+    void *d;        /* [S][B][T][n] Newton update */
+    void *phi;      /* [S][n_ls][B] candidate merits */
+    void *phi_prev; /* [S][B] */
+    int *k;         /* [S][B] chosen candidate */
+    int *accept;    /* [S][B] */
+} AlqpTrace;
+
+#define ALQP_E_BADARG     (-1)
+#define ALQP_E_UNSUPPORTED (-2)  /* (nx,nu) not instantiated or LDS budget exceeded */
+#define ALQP_E_LAUNCH     (-3)
+
+/* 1 if (nx,nu) has a compiled kernel instance and the horizon fits in LDS. */
+int alqp_supported(const AlqpDims *dims, int is_f64);
+/* LDS bytes one workgroup of the fused kernel uses (0 if unsupported). */
+size_t alqp_lds_bytes(const AlqpDims *dims, int is_f64);
+/* QP instances one 64-lane wavefront solves concurrently. */
+int alqp_qps_per_wave(const AlqpDims *dims, int is_f64);
+
+/*
+ * Fused solve on affine ("LinDx") dynamics x_{t+1} = F_t [x_t;u_t] + c_t.
+ * Replaces MPC.al_solve (qpth/AL_mpc.py:260-339) + NewtonAL.forward
+ * (qpth/al_utils.py:451-576) + line_search_newton (:618-642) for one batch:
+ * al_iter x [merit init; max_newton x (gradient, block-tridiagonal Cholesky,
+ * Newton step, 20-point line search); dual update + projection; rho *= rho_scale].
+ *   in/out: z (start iterate -> solution), lam, rho, phi (merit carried between
+ *           calls when ALQP_INIT_MERIT is off)
+ *   out   : rnorm2[B] = sum r+(z)^2 (what the reference's batch-global exit test
+ *           sums, al_utils.py:552), info[B] (0 or stage*n+pivot+1 of the first
+ *           non-positive pivot), status[B] (1 = iterate finite, al_utils.py:545-549),
+ *           factor_out (nullable), trace (nullable)
+ */
+int alqp_solve_lin_f32(const AlqpDims *dims, const AlqpParams *prm, const void *Qd, const void *q,
+                       const void *F, const void *c, const void *x0, const void *u_lo,
+                       const void *u_hi, long sb_u, long st_u, void *z, void *lam, void *rho,
+                       void *phi, void *rnorm2, int *info, unsigned char *status,
+                       void *factor_out, const AlqpTrace *trace, void *stream);
+int alqp_solve_lin_f64(const AlqpDims *dims, const AlqpParams *prm, const void *Qd, const void *q,
+                       const void *F, const void *c, const void *x0, const void *u_lo,
+                       const void *u_hi, long sb_u, long st_u, void *z, void *lam, void *rho,
+                       void *phi, void *rnorm2, int *info, unsigned char *status,
+                       void *factor_out, const AlqpTrace *trace, void *stream);
+
+/*
+ * One Newton direction for the nonlinear-caller mode: the caller evaluated
+ * dx_jac(x,u) -> (xnext, F) in PyTorch (al_utils.py:233-248). Replaces
+ * merit_grad_hessian (:80-123) + cholesky_ex/cholesky_solve (:510-515).
+ *   out: d[B][T][n] = -H^{-1} g, g_out (nullable), factor_out (nullable), info[B]
+ */
+int alqp_newton_step_f32(const AlqpDims *dims, const void *z, const void *xnext, const void *F,
+                         const void *x0, const void *lam, const void *rho, const void *Qd,
+                         const void *q, const void *u_lo, const void *u_hi, long sb_u, long st_u,
+                         void *d_out, void *g_out, void *factor_out, int *info, void *stream);
+int alqp_newton_step_f64(const AlqpDims *dims, const void *z, const void *xnext, const void *F,
+                         const void *x0, const void *lam, const void *rho, const void *Qd,
+                         const void *q, const void *u_lo, const void *u_hi, long sb_u, long st_u,
+                         void *d_out, void *g_out, void *factor_out, int *info, void *stream);
+
+/*
+ * Merit of K stacked candidates (al_utils.py:52-77 with the [K,B,T,n] broadcast of
+ * :56-70): zc[K][B][T][n], xnext[K][B][T-1][nx] -> phi[K][B], rnorm2[K][B] (nullable).
+ */
+int alqp_merit_f32(const AlqpDims *dims, int K, const void *zc, const void *xnext, const void *x0,
+                   const void *lam, const void *rho, const void *Qd, const void *q,
+                   const void *u_lo, const void *u_hi, long sb_u, long st_u, void *phi,
+                   void *rnorm2, void *stream);
+int alqp_merit_f64(const AlqpDims *dims, int K, const void *zc, const void *xnext, const void *x0,
+                   const void *lam, const void *rho, const void *Qd, const void *q,
+                   const void *u_lo, const void *u_hi, long sb_u, long st_u, void *phi,
+                   void *rnorm2, void *stream);
+
+/*
+ * Line-search decision + update (al_utils.py:634-641): first argmin over phi[n_ls][B],
+ * accept iff strictly below phi_prev; z <- accept ? z + 2^-k d : z (in place);
+ * phi_prev <- phi_min regardless (al_utils.py:569). k_out/accept_out nullable.
+ */
+int alqp_linesearch_pick_f32(const AlqpDims *dims, int n_ls, const void *phi, void *phi_prev,
+                             const void *d, void *z, int *k_out, int *accept_out, void *stream);
+int alqp_linesearch_pick_f64(const AlqpDims *dims, int n_ls, const void *phi, void *phi_prev,
+                             const void *d, void *z, int *k_out, int *accept_out, void *stream);
+
+/*
+ * Dual update + projection + penalty growth (AL_mpc.py:315-317, 325) given
+ * xnext = f(x_t,u_t) at the final iterate; lam, rho updated in place.
+ */
+int alqp_dual_update_f32(const AlqpDims *dims, const void *z, const void *xnext, const void *x0,
+                         const void *u_lo, const void *u_hi, long sb_u, long st_u, void *lam,
+                         void *rho, double rho_scale, void *stream);
+int alqp_dual_update_f64(const AlqpDims *dims, const void *z, const void *xnext, const void *x0,
+                         const void *u_lo, const void *u_hi, long sb_u, long st_u, void *lam,
+                         void *rho, double rho_scale, void *stream);
+
+/*
+ * Backward of the implicit layer (NewtonAL.backward, al_utils.py:578-615):
+ * w = -H^{-1} gbar with the saved factor; q_grad = w, Qd_grad = w * z_final.
+ * rho is the penalty the factor was built with.
+ */
+int alqp_backward_f32(const AlqpDims *dims, const void *factor, const void *F, const void *rho,
+                      const void *z_final, const void *gbar, void *q_grad, void *Qd_grad,
+                      void *stream);
+int alqp_backward_f64(const AlqpDims *dims, const void *factor, const void *F, const void *rho,
+                      const void *z_final, const void *gbar, void *q_grad, void *Qd_grad,
+                      void *stream);
+
+/* Library/ABI version, bumped when a signature changes. */
+int alqp_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MI_ALQP_H */
