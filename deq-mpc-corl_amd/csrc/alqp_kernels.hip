@@ -9,44 +9,54 @@
 
 namespace alqp {
 
+// Kernel arguments are kept lean on purpose: every pointer is two SGPRs for the whole
+// kernel, and SGPR spills (v_writelane/v_readlane) showed up in the hot loops otherwise.
 template <typename real>
 struct SolveArgs {
     int B, T;
     int al_iter, max_newton, n_ls, flags;
     real rho_scale;
-    const real *Qd, *q, *F, *c, *x0, *ulo, *uhi, *xnext;
+    const real *Qd, *q, *F, *c, *x0, *ulo, *uhi;
     long sb_u, st_u;
     real *z, *lam, *rho, *phi, *rnorm2;
     int *info;
     unsigned char *status;
     real *factor;
-    // trace
-    real *tr_g, *tr_d, *tr_phi, *tr_phi_prev;
-    int *tr_k, *tr_accept;
-    // newton_step / backward extras
-    real *d_out, *g_out;
-    const real *gbar, *z_final;
+};
+
+template <typename real>
+struct TraceArgs {
+    real *g, *d, *phi, *phi_prev;
+    int *k, *accept;
+};
+
+template <typename real>
+struct StepArgs {
+    int B, T;
+    const real *z, *xnext, *F, *x0, *lam, *rho, *Qd, *q, *ulo, *uhi;
+    long sb_u, st_u;
+    real *d_out, *g_out, *factor;
+    int *info;
+};
+
+template <typename real>
+struct BwdArgs {
+    int B, T;
+    const real *factor, *F, *rho, *z_final, *gbar;
     real *q_grad, *Qd_grad;
 };
 
-template <typename real, int NX, int NU>
-__device__ inline void bind_instance(Team<real, NX, NU> &tm, const SolveArgs<real> &a, int b) {
-    constexpr int N = NX + NU;
-    const int T = a.T;
-    tm.gQd = a.Qd ? a.Qd + (size_t)b * T * N : nullptr;
-    tm.gq = a.q ? a.q + (size_t)b * T * N : nullptr;
-    tm.gF = a.F ? a.F + (size_t)b * (T - 1) * NX * N : nullptr;
-    tm.gc = a.c ? a.c + (size_t)b * (T - 1) * NX : nullptr;
-    tm.gx0 = a.x0 ? a.x0 + (size_t)b * NX : nullptr;
-    tm.gulo = a.ulo ? a.ulo + (size_t)b * a.sb_u : nullptr;
-    tm.guhi = a.uhi ? a.uhi + (size_t)b * a.sb_u : nullptr;
-    tm.st_u = a.st_u;
-    tm.gxnext = a.xnext ? a.xnext + (size_t)b * (T - 1) * NX : nullptr;
+// A VGPR zero the compiler cannot see through: keeps LDS addresses "divergent", so that
+// wave-uniform operand reads stay 16-byte vector ds_reads instead of being scalarised.
+__device__ inline unsigned opaque_zero() {
+    unsigned z;
+    asm volatile("v_mov_b32 %0, 0" : "=v"(z));
+    return z;
 }
 
 // ---- fused LinDx solve -------------------------------------------------------------
-template <typename real, int NX, int NU>
-__global__ __launch_bounds__(64) void k_solve_lin(SolveArgs<real> a) {
+template <typename real, int NX, int NU, bool TRACE>
+__global__ __launch_bounds__(64) void k_solve_lin(SolveArgs<real> a, TraceArgs<real> tr) {
     using C = Cfg<real, NX, NU>;
     constexpr int G = C::G, N = C::N;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -58,8 +68,15 @@ __global__ __launch_bounds__(64) void k_solve_lin(SolveArgs<real> a) {
     const int T = a.T, M = C::M(T), neq = T * NX;
 
     Team<real, NX, NU> tm;
-    tm.init(smem + (size_t)team * C::team_words(T), li, team * G, T, b);
-    bind_instance(tm, a, b);
+    tm.init(smem + (size_t)team * C::team_words(T) + opaque_zero(), li, team * G, T, b);
+    tm.gQd = a.Qd + (size_t)b * T * N;
+    tm.gq = a.q + (size_t)b * T * N;
+    tm.gF = a.F + (size_t)b * (T - 1) * NX * N;
+    tm.gc = a.c + (size_t)b * (T - 1) * NX;
+    tm.gx0 = a.x0 + (size_t)b * NX;
+    tm.gulo = a.ulo + (size_t)b * a.sb_u;
+    tm.guhi = a.uhi + (size_t)b * a.sb_u;
+    tm.st_u = a.st_u;
 
     real *gz = a.z + (size_t)b * T * N;
     real *glam = a.lam + (size_t)b * M;
@@ -78,12 +95,15 @@ __global__ __launch_bounds__(64) void k_solve_lin(SolveArgs<real> a) {
             phi_prev = p1[0];
         }
         for (int st = 0; st < a.max_newton; ++st, ++step_id) {
-            real *tg = a.tr_g ? a.tr_g + ((size_t)step_id * a.B + b) * T * N : nullptr;
-            tm.forward_sweep(active ? tg : nullptr);
+            real *tg = nullptr;
+            if constexpr (TRACE) tg = (tr.g && active) ? tr.g + ((size_t)step_id * a.B + b) * T * N : nullptr;
+            tm.forward_sweep(tg);
             tm.backward_sweep();
-            if (a.tr_d && active) {
-                real *td = a.tr_d + ((size_t)step_id * a.B + b) * T * N;
-                for (int e = li; e < T * N; e += G) td[e] = tm.ds[e];
+            if constexpr (TRACE) {
+                if (tr.d && active) {
+                    real *td = tr.d + ((size_t)step_id * a.B + b) * T * N;
+                    for (int e = li; e < T * N; e += G) td[e] = tm.ds[e];
+                }
             }
             real ph[20];
             tm.template merit_candidates<20>(ph, false);
@@ -97,14 +117,16 @@ __global__ __launch_bounds__(64) void k_solve_lin(SolveArgs<real> a) {
                 }
             }
             const bool acc = best < phi_prev;
-            if (active && li == 0) {
-                if (a.tr_phi)
+            if constexpr (TRACE) {
+                if (active && li == 0) {
+                    if (tr.phi)
 #pragma unroll
-                    for (int k = 0; k < 20; ++k)
-                        if (k < a.n_ls) a.tr_phi[((size_t)step_id * a.n_ls + k) * a.B + b] = ph[k];
-                if (a.tr_phi_prev) a.tr_phi_prev[(size_t)step_id * a.B + b] = phi_prev;
-                if (a.tr_k) a.tr_k[(size_t)step_id * a.B + b] = kbest;
-                if (a.tr_accept) a.tr_accept[(size_t)step_id * a.B + b] = acc ? 1 : 0;
+                        for (int k = 0; k < 20; ++k)
+                            if (k < a.n_ls) tr.phi[((size_t)step_id * a.n_ls + k) * a.B + b] = ph[k];
+                    if (tr.phi_prev) tr.phi_prev[(size_t)step_id * a.B + b] = phi_prev;
+                    if (tr.k) tr.k[(size_t)step_id * a.B + b] = kbest;
+                    if (tr.accept) tr.accept[(size_t)step_id * a.B + b] = acc ? 1 : 0;
+                }
             }
             const real alpha = acc ? real(1) / real(1 << kbest) : real(0);
             for (int e = li; e < T * N; e += G) tm.zs[e] += alpha * tm.ds[e];
@@ -144,7 +166,7 @@ __global__ __launch_bounds__(64) void k_solve_lin(SolveArgs<real> a) {
 
 // ---- one Newton direction (nonlinear-caller mode) ----------------------------------
 template <typename real, int NX, int NU>
-__global__ __launch_bounds__(64) void k_newton_step(SolveArgs<real> a) {
+__global__ __launch_bounds__(64) void k_newton_step(StepArgs<real> a) {
     using C = Cfg<real, NX, NU>;
     constexpr int G = C::G, N = C::N;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -156,8 +178,16 @@ __global__ __launch_bounds__(64) void k_newton_step(SolveArgs<real> a) {
     const int T = a.T, M = C::M(T);
 
     Team<real, NX, NU> tm;
-    tm.init(smem + (size_t)team * C::team_words(T), li, team * G, T, b);
-    bind_instance(tm, a, b);
+    tm.init(smem + (size_t)team * C::team_words(T) + opaque_zero(), li, team * G, T, b);
+    tm.gQd = a.Qd + (size_t)b * T * N;
+    tm.gq = a.q + (size_t)b * T * N;
+    tm.gF = a.F + (size_t)b * (T - 1) * NX * N;
+    tm.gc = nullptr;
+    tm.gx0 = a.x0 + (size_t)b * NX;
+    tm.gulo = a.ulo + (size_t)b * a.sb_u;
+    tm.guhi = a.uhi + (size_t)b * a.sb_u;
+    tm.st_u = a.st_u;
+    tm.gxnext = a.xnext + (size_t)b * (T - 1) * NX;
     const real *gz = a.z + (size_t)b * T * N;
     const real *glam = a.lam + (size_t)b * M;
     for (int e = li; e < T * N; e += G) tm.zs[e] = gz[e];
@@ -179,7 +209,7 @@ __global__ __launch_bounds__(64) void k_newton_step(SolveArgs<real> a) {
 
 // ---- backward of the implicit layer -------------------------------------------------
 template <typename real, int NX, int NU>
-__global__ __launch_bounds__(64) void k_backward(SolveArgs<real> a) {
+__global__ __launch_bounds__(64) void k_backward(BwdArgs<real> a) {
     using C = Cfg<real, NX, NU>;
     constexpr int G = C::G, N = C::N;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -191,8 +221,8 @@ __global__ __launch_bounds__(64) void k_backward(SolveArgs<real> a) {
     const int T = a.T;
 
     Team<real, NX, NU> tm;
-    tm.init(smem + (size_t)team * C::team_words(T), li, team * G, T, b);
-    bind_instance(tm, a, b);
+    tm.init(smem + (size_t)team * C::team_words(T) + opaque_zero(), li, team * G, T, b);
+    tm.gF = a.F + (size_t)b * (T - 1) * NX * N;
     const real *gf = a.factor + (size_t)b * T * C::XT;
     const real *gg = a.gbar + (size_t)b * T * N;
     for (int e = li; e < T * C::XT; e += G) tm.Xp[e] = gf[e];
@@ -339,39 +369,53 @@ __global__ __launch_bounds__(64) void k_dual(AuxArgs<real> a) {
 
 constexpr size_t kMaxLds = 160 * 1024;
 
-enum KernelId { KID_SOLVE, KID_STEP, KID_BACKWARD };
-
 template <typename real, int NX, int NU>
 size_t lds_bytes_for(int T) {
     using C = Cfg<real, NX, NU>;
     return (size_t)C::QPW * C::team_words(T) * sizeof(real);
 }
 
-template <typename real, int NX, int NU>
-int launch_one(KernelId kid, const SolveArgs<real> &a, hipStream_t stream) {
+// Launches `fn` with one wavefront per workgroup and the team LDS image as dynamic LDS.
+template <typename real, int NX, int NU, typename Fn, typename... Args>
+int launch_team_kernel(Fn fn, int B, int T, hipStream_t stream, Args... args) {
     using C = Cfg<real, NX, NU>;
-    const size_t lds = lds_bytes_for<real, NX, NU>(a.T);
+    const size_t lds = lds_bytes_for<real, NX, NU>(T);
     if (lds > kMaxLds) return ALQP_E_UNSUPPORTED;
-    const unsigned grid = (unsigned)((a.B + C::QPW - 1) / C::QPW);
-    void (*fn)(SolveArgs<real>) = nullptr;
-    switch (kid) {
-        case KID_SOLVE: fn = k_solve_lin<real, NX, NU>; break;
-        case KID_STEP: fn = k_newton_step<real, NX, NU>; break;
-        case KID_BACKWARD: fn = k_backward<real, NX, NU>; break;
-    }
+    const unsigned grid = (unsigned)((B + C::QPW - 1) / C::QPW);
     if (lds > 48 * 1024) {
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(fn),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return ALQP_E_LAUNCH;
     }
-    hipLaunchKernelGGL(fn, dim3(grid), dim3(64), lds, stream, a);
+    hipLaunchKernelGGL(fn, dim3(grid), dim3(64), lds, stream, args...);
     return hipGetLastError() == hipSuccess ? 0 : ALQP_E_LAUNCH;
 }
 
 template <typename real>
-int dispatch(KernelId kid, int nx, int nu, const SolveArgs<real> &a, hipStream_t stream) {
+int dispatch_solve(int nx, int nu, const SolveArgs<real> &a, const TraceArgs<real> *tr, hipStream_t stream) {
+#define X(NX, NU)                                                                                     \
+    if (nx == NX && nu == NU) {                                                                       \
+        if (tr) return launch_team_kernel<real, NX, NU>(k_solve_lin<real, NX, NU, true>, a.B, a.T, stream, a, *tr); \
+        return launch_team_kernel<real, NX, NU>(k_solve_lin<real, NX, NU, false>, a.B, a.T, stream, a, TraceArgs<real>{}); \
+    }
+    ALQP_FOR_EACH_DIMS(X)
+#undef X
+    return ALQP_E_UNSUPPORTED;
+}
+
+template <typename real>
+int dispatch_step(int nx, int nu, const StepArgs<real> &a, hipStream_t stream) {
 #define X(NX, NU) \
-    if (nx == NX && nu == NU) return launch_one<real, NX, NU>(kid, a, stream);
+    if (nx == NX && nu == NU) return launch_team_kernel<real, NX, NU>(k_newton_step<real, NX, NU>, a.B, a.T, stream, a);
+    ALQP_FOR_EACH_DIMS(X)
+#undef X
+    return ALQP_E_UNSUPPORTED;
+}
+
+template <typename real>
+int dispatch_backward(int nx, int nu, const BwdArgs<real> &a, hipStream_t stream) {
+#define X(NX, NU) \
+    if (nx == NX && nu == NU) return launch_team_kernel<real, NX, NU>(k_backward<real, NX, NU>, a.B, a.T, stream, a);
     ALQP_FOR_EACH_DIMS(X)
 #undef X
     return ALQP_E_UNSUPPORTED;
@@ -415,11 +459,12 @@ int solve_lin_impl(const AlqpDims *dims, const AlqpParams *prm, const void *Qd, 
     a.sb_u = sb_u; a.st_u = st_u;
     a.z = (real *)z; a.lam = (real *)lam; a.rho = (real *)rho; a.phi = (real *)phi;
     a.rnorm2 = (real *)rnorm2; a.info = info; a.status = status; a.factor = (real *)factor_out;
+    TraceArgs<real> tr = {};
     if (trace) {
-        a.tr_g = (real *)trace->g; a.tr_d = (real *)trace->d; a.tr_phi = (real *)trace->phi;
-        a.tr_phi_prev = (real *)trace->phi_prev; a.tr_k = trace->k; a.tr_accept = trace->accept;
+        tr.g = (real *)trace->g; tr.d = (real *)trace->d; tr.phi = (real *)trace->phi;
+        tr.phi_prev = (real *)trace->phi_prev; tr.k = trace->k; tr.accept = trace->accept;
     }
-    return dispatch<real>(KID_SOLVE, dims->nx, dims->nu, a, (hipStream_t)stream);
+    return dispatch_solve<real>(dims->nx, dims->nu, a, trace ? &tr : nullptr, (hipStream_t)stream);
 }
 
 template <typename real>
@@ -429,14 +474,13 @@ int newton_step_impl(const AlqpDims *dims, const void *z, const void *xnext, con
                      void *g_out, void *factor_out, int *info, void *stream) {
     if (!dims_ok(dims) || !z || !xnext || !F || !x0 || !lam || !rho || !Qd || !q || !u_lo || !u_hi || !d_out)
         return ALQP_E_BADARG;
-    SolveArgs<real> a = {};
+    StepArgs<real> a = {};
     a.B = dims->B; a.T = dims->T;
-    a.Qd = (const real *)Qd; a.q = (const real *)q; a.F = (const real *)F; a.x0 = (const real *)x0;
+    a.z = (const real *)z; a.xnext = (const real *)xnext; a.F = (const real *)F; a.x0 = (const real *)x0;
+    a.lam = (const real *)lam; a.rho = (const real *)rho; a.Qd = (const real *)Qd; a.q = (const real *)q;
     a.ulo = (const real *)u_lo; a.uhi = (const real *)u_hi; a.sb_u = sb_u; a.st_u = st_u;
-    a.xnext = (const real *)xnext;
-    a.z = (real *)z; a.lam = (real *)lam; a.rho = (real *)rho;
     a.d_out = (real *)d_out; a.g_out = (real *)g_out; a.factor = (real *)factor_out; a.info = info;
-    return dispatch<real>(KID_STEP, dims->nx, dims->nu, a, (hipStream_t)stream);
+    return dispatch_step<real>(dims->nx, dims->nu, a, (hipStream_t)stream);
 }
 
 template <typename real>
@@ -444,12 +488,12 @@ int backward_impl(const AlqpDims *dims, const void *factor, const void *F, const
                   const void *z_final, const void *gbar, void *q_grad, void *Qd_grad, void *stream) {
     if (!dims_ok(dims) || !factor || !F || !rho || !z_final || !gbar || !q_grad || !Qd_grad)
         return ALQP_E_BADARG;
-    SolveArgs<real> a = {};
+    BwdArgs<real> a = {};
     a.B = dims->B; a.T = dims->T;
-    a.F = (const real *)F; a.rho = (real *)rho; a.factor = (real *)factor;
-    a.gbar = (const real *)gbar; a.z_final = (const real *)z_final;
+    a.factor = (const real *)factor; a.F = (const real *)F; a.rho = (const real *)rho;
+    a.z_final = (const real *)z_final; a.gbar = (const real *)gbar;
     a.q_grad = (real *)q_grad; a.Qd_grad = (real *)Qd_grad;
-    return dispatch<real>(KID_BACKWARD, dims->nx, dims->nu, a, (hipStream_t)stream);
+    return dispatch_backward<real>(dims->nx, dims->nu, a, (hipStream_t)stream);
 }
 
 template <typename real>

@@ -3,26 +3,32 @@
 // MI355X / gfx950 only. A team is G consecutive lanes of a 64-lane wavefront
 // (G = 8/16/32/64, the smallest power of two holding NROWS = 2n+nx+1 lanes);
 // 64/G instances share a wavefront and a workgroup is exactly one wavefront, so
-// every synchronisation below is wave-local.
+// every synchronisation below is wave-local: LDS instructions of one wave execute in
+// issue order, so a ds_write followed by a ds_read of another lane's word needs no
+// barrier, only a compiler fence (wave_sync) that keeps the two in program order.
 //
 // The Newton system H d = -g of the AL merit (qpth/al_utils.py:80-123) is block
 // tridiagonal: n x n diagonal blocks H_tt and sub-diagonal blocks
 // H_{t+1,t} = -rho E'F_t whose only non-zero rows are the first nx. The team sweeps the
 // horizon once forward (factor + forward substitution) and once backward.
 //
-// Forward stage t is ONE left-looking panel factorisation with a lane per panel row:
-//   lanes [0,n)            rows of H_tt            -> L_tt            (Cholesky)
-//   lanes [n,n+nx)         rows of -rho F_t        -> W_t = H_{t+1,t} L_tt^{-T}
-//   lane  n+nx             the right-hand side -g_t -> y_t            (forward subst.)
-//   lanes (n+nx,2n+nx]     rows of the identity    -> X_t = L_tt^{-T} (explicit inverse)
-// Every lane does the same arithmetic on its own row held in registers:
-//   row[j] = (row0[j] + rho*<Fcol_row,Fcol_j> - <Wprev_row,Wprev_j> - sum_{k<j} row[k] L[j][k]) / L[j][j]
-// and only "row j" operands are broadcast (LDS reads at a wave-uniform address, no
-// bank conflicts). H_tt is never materialised: its F'F term and the Schur complement
-// W_{t-1}W_{t-1}' of the previous stage are folded into the same dot products.
+// Forward stage t:
+//  (1) SYRK phase, 2x2 output blocks spread over the lanes (lower triangle only):
+//        Hs = rho * Ft Ft' - Sb Sb'
+//      with Ft = [F_t' ; 0] (rows = columns of F_t) and Sb = [W_{t-1} ; 0 ; y_{t-1}'],
+//      i.e. the F'F term of H_tt, the Schur complement W_{t-1}W_{t-1}' of the previous
+//      stage AND the coupling W_{t-1} y_{t-1} of the right-hand side in one pass.
+//      Operands are read from LDS as 16-byte vectors.
+//  (2) panel phase, a lane per panel row, rows in registers:
+//        lanes [0,n)          rows of H_tt          -> L_tt            (Cholesky)
+//        lanes [n,n+nx)       rows of -rho F_t      -> W_t = H_{t+1,t} L_tt^{-T}
+//        lane  n+nx           right-hand side -g_t  -> y_t             (forward subst.)
+//        lanes (n+nx,2n+nx]   rows of the identity  -> X_t = L_tt^{-T} (explicit inverse)
+//      left-looking: row[j] = (row[j] - sum_{k<j} row[k] L[j][k]) / L[j][j]; the L[j][k]
+//      operands come straight out of lane j's registers (v_readlane, no LDS round trip).
 // Only X_t (packed, n(n+1)/2 words per stage) is kept in LDS for the backward sweep,
 // which is then pure mat-vec work (no serial triangular solves):
-//   d_t = X_t ( y_t + rho * X_t' F_t' dx_{t+1} ).
+//        d_t = X_t ( y_t + rho * X_t' F_t' dx_{t+1} ).
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -39,14 +45,19 @@ struct Cfg {
     static constexpr int G = NROWS <= 8 ? 8 : NROWS <= 16 ? 16 : NROWS <= 32 ? 32 : 64;
     static constexpr int QPW = 64 / G;          // instances per wavefront
     static constexpr int XT = N * (N + 1) / 2;  // packed upper triangle of X_t
+    static constexpr int NB = (N + 2) / 2;      // 2x2 block rows covering rows 0..N (N = rhs row)
+    static constexpr int RB = 2 * NB;
+    static constexpr int NBLK = NB * (NB + 1) / 2;
+    static constexpr int HP = pad4(RB);         // row stride of Hs: the 2x2 blocks span RB columns
+    static_assert(NBLK <= G, "SYRK blocks must fit the team");
     // per-team LDS scratch, offsets in reals (all multiples of 4 -> 16-byte aligned)
-    static constexpr int oFs = 0;                      // raw F_t            [NX*N]
-    static constexpr int oFt = oFs + pad4(NX * N);     // F_t transposed     [N][NXP]
-    static constexpr int oWb = oFt + N * NXP;          // W_{t-1}, W_t       [2][NX][NP]
-    static constexpr int oLw = oWb + 2 * NX * NP;      // rows of L_tt       [N][NP]
-    static constexpr int oVs = oLw + N * NP;           // nx-vector          [NXP]
-    static constexpr int oGs = oVs + NXP;              // n-vector           [NP]
-    static constexpr int oRs = oGs + NP;               // n-vector           [NP]
+    static constexpr int oFs = 0;                      // raw F_t                    [NX*N]
+    static constexpr int oFt = oFs + pad4(NX * N);     // [F_t' ; 0]                 [RB][NXP]
+    static constexpr int oSb = oFt + RB * NXP;         // [W_{t-1} ; 0 ; y_{t-1}']   [RB][NP]
+    static constexpr int oHs = oSb + RB * NP;          // SYRK result, then identity [RB+N][HP]
+    static constexpr int oVs = oHs + (RB + N) * HP;    // nx-vector                  [NXP]
+    static constexpr int oGs = oVs + NXP;              // n-vector                   [NP]
+    static constexpr int oRs = oGs + NP;               // n-vector                   [NP]
     static constexpr int SCRATCH = oRs + NP;
     __host__ __device__ static constexpr int M(int T) { return T * NX + 2 * T * NU; }
     // persistent arrays: z, d (y), r_eq, s_eq = (J d)_eq, lam, X
@@ -55,7 +66,41 @@ struct Cfg {
     }
 };
 
-// ---- cross-lane helpers ----------------------------------------------------------
+// ---- small helpers ---------------------------------------------------------------
+
+__device__ inline float fma_(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+__device__ inline double fma_(double a, double b, double c) { return __builtin_fma(a, b, c); }
+
+// 1/sqrt(p): fp32 uses v_rsq_f32 (<= 1 ulp), fp64 the correctly rounded sequence
+__device__ inline float rsqrt_(float p) { return __builtin_amdgcn_rsqf(p); }
+__device__ inline double rsqrt_(double p) { return 1.0 / __builtin_sqrt(p); }
+
+// v if d >= 0 else +0, without a lane-mask compare (loop-invariant compares get hoisted
+// into SGPR pairs by the compiler and then spilled: 2 SGPRs per unrolled index)
+__device__ inline float keep_if_nonneg(float v, int d) {
+    return __builtin_bit_cast(float, __builtin_bit_cast(int, v) & ~(d >> 31));
+}
+__device__ inline double keep_if_nonneg(double v, int d) {
+    return __builtin_bit_cast(double, __builtin_bit_cast(long long, v) & ~(long long)(d >> 31));
+}
+
+// 16-byte LDS vector access (p must be 16-byte aligned)
+__device__ inline void ld4(const float *p, float (&v)[4]) {
+    float4 t = *reinterpret_cast<const float4 *>(p);
+    v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+}
+__device__ inline void ld4(const double *p, double (&v)[4]) {
+    double2 a = *reinterpret_cast<const double2 *>(p);
+    double2 b = *reinterpret_cast<const double2 *>(p + 2);
+    v[0] = a.x; v[1] = a.y; v[2] = b.x; v[3] = b.y;
+}
+__device__ inline void st4(float *p, float a, float b, float c, float d) {
+    *reinterpret_cast<float4 *>(p) = make_float4(a, b, c, d);
+}
+__device__ inline void st4(double *p, double a, double b, double c, double d) {
+    *reinterpret_cast<double2 *>(p) = make_double2(a, b);
+    *reinterpret_cast<double2 *>(p + 2) = make_double2(c, d);
+}
 
 template <int G>
 __device__ inline float team_bcast(float v, int src_in_team, int team_base) {
@@ -90,7 +135,8 @@ __device__ inline int team_or(int v) {
     return v;
 }
 
-__device__ inline void wave_sync() { __syncthreads(); }  // workgroup == one wavefront
+// Compiler-only fence: LDS traffic of one wave is executed in order by the hardware.
+__device__ inline void wave_sync() { asm volatile("" ::: "memory"); }
 
 // ---- the team -------------------------------------------------------------------
 
@@ -98,24 +144,27 @@ template <typename real, int NX, int NU>
 struct Team {
     using C = Cfg<real, NX, NU>;
     static constexpr int N = C::N, NP = C::NP, NXP = C::NXP, G = C::G, XT = C::XT;
+    static constexpr int RB = C::RB, HP = C::HP;
 
     // LDS
-    real *Fs, *Ft, *Wb, *Lw, *vs, *gs, *rs;
+    real *Fs, *Ft, *Sb, *Hs, *vs, *gs, *rs;
     real *zs, *ds, *req, *seq, *lams, *Xp;
     // identity
     int li, team_base, T, b;
-    bool isH, isW, isY, isU;
-    int hi, wr, ui, jmin, jmax;
+    bool isH, isW, isY, isU, isBlk;
+    int hi, wr, ui, bi, bj;
     // problem (global memory, this instance)
     const real *gQd, *gq, *gF, *gc, *gx0, *gulo, *guhi, *gxnext;
     long st_u;
     real rho;
     int info;
 
+    // `lds_team` must not be provably wave-uniform (see the kernels): uniform LDS reads
+    // get scalarised by the compiler into ds_read + v_readfirstlane + SGPR-spill chains.
     __device__ void init(real *lds_team, int lane_in_team, int team_base_, int T_, int b_) {
         li = lane_in_team; team_base = team_base_; T = T_; b = b_;
-        Fs = lds_team + C::oFs; Ft = lds_team + C::oFt; Wb = lds_team + C::oWb;
-        Lw = lds_team + C::oLw; vs = lds_team + C::oVs; gs = lds_team + C::oGs; rs = lds_team + C::oRs;
+        Fs = lds_team + C::oFs; Ft = lds_team + C::oFt; Sb = lds_team + C::oSb;
+        Hs = lds_team + C::oHs; vs = lds_team + C::oVs; gs = lds_team + C::oGs; rs = lds_team + C::oRs;
         real *p = lds_team + C::SCRATCH;
         zs = p; p += pad4(T * N);
         ds = p; p += pad4(T * N);
@@ -126,20 +175,50 @@ struct Team {
         isH = li < N; isW = li >= N && li < N + NX; isY = li == N + NX;
         isU = li > N + NX && li < C::NROWS;
         hi = isH ? li : 0; wr = isW ? li - N : 0; ui = isU ? li - (N + NX + 1) : 0;
-        // row entries kept after the column step j: jmin <= j <= jmax
-        jmin = isU ? ui : 0;
-        jmax = isH ? hi : ((isW || isY || isU) ? N - 1 : -1);
+        // SYRK block owned by this lane: lower-triangular enumeration (bi >= bj)
+        isBlk = li < C::NBLK;
+        bi = 0; bj = 0;
+        {
+            int rem = isBlk ? li : 0;
+            while (rem > bi) { rem -= bi + 1; ++bi; }
+            bj = rem;
+        }
         info = 0;
         gxnext = nullptr;
+        // constant zero rows / pads of the SYRK operands
+        for (int e = li; e < RB * NXP; e += G) Ft[e] = 0;
+        for (int e = li; e < RB * NP; e += G) Sb[e] = 0;
+        for (int e = li; e < RB * HP; e += G) Hs[e] = 0;
+        for (int e = li; e < N * HP; e += G) Hs[RB * HP + e] = (e / HP == e % HP) ? real(1) : real(0);
+        for (int e = li; e < NXP; e += G) vs[e] = 0;
+        for (int e = li; e < NP; e += G) gs[e] = 0;
+        wave_sync();
     }
 
     __device__ real uhi(int t, int j) const { return guhi[t * st_u + j]; }
     __device__ real ulo(int t, int j) const { return gulo[t * st_u + j]; }
 
-    // coalesced copy of F_t into LDS (raw row-major [NX][N])
-    __device__ void load_F(int t) {
+    static constexpr int FCH = (NX * N + G - 1) / G;  // F words per lane
+
+    __device__ void fetch_F(int t, real (&buf)[FCH]) const {
         const real *Fg = gF + (size_t)t * NX * N;
-        for (int e = li; e < NX * N; e += G) Fs[e] = Fg[e];
+#pragma unroll
+        for (int i = 0; i < FCH; ++i) {
+            int e = li + i * G;
+            buf[i] = e < NX * N ? Fg[e] : real(0);
+        }
+    }
+    __device__ void stash_F(const real (&buf)[FCH]) {
+#pragma unroll
+        for (int i = 0; i < FCH; ++i) {
+            int e = li + i * G;
+            if (e < NX * N) Fs[e] = buf[i];
+        }
+    }
+    __device__ void load_F(int t) {
+        real buf[FCH];
+        fetch_F(t, buf);
+        stash_F(buf);
     }
 
     // equality residual of every stage at the current zs -> req (kernel start)
@@ -152,10 +231,10 @@ struct Team {
                 load_F(t);
                 wave_sync();
                 if (isW) {
-                    real s = 0;
+                    real s = gc[t * NX + wr];
 #pragma unroll
-                    for (int k = 0; k < N; ++k) s += Fs[wr * N + k] * zs[t * N + k];
-                    xn = s + gc[t * NX + wr];
+                    for (int k = 0; k < N; ++k) s = fma_(Fs[wr * N + k], zs[t * N + k], s);
+                    xn = s;
                 }
             }
             if (isW) req[t * NX + wr] = zs[(t + 1) * N + wr] - xn;
@@ -168,160 +247,200 @@ struct Team {
     // Forward sweep: gradient, factorisation and forward substitution, stage by stage.
     // Leaves y_t in ds[t], X_t in Xp[t], r_eq in req. g_out (nullable, global [T][N]).
     __device__ void forward_sweep(real *g_out) {
-        real l[N], fa[N], bb[N];
-#pragma unroll
-        for (int k = 0; k < N; ++k) bb[k] = 0;
+        real l[N], fa[N];
+        real fbuf[FCH];
         // initial-state residual (eq row block T-1), al_utils.py:274
         if (li < NX) req[(T - 1) * NX + li] = zs[li] - gx0[li];
+        fetch_F(0, fbuf);
+        real Qn = isH ? gQd[hi] : real(0), qn = isH ? gq[hi] : real(0);
+        real cn = isW ? (gxnext ? gxnext[wr] : gc[wr]) : real(0);
         for (int t = 0; t < T; ++t) {
             const bool dyn = t < T - 1;
-            const int cur = t & 1, prev = cur ^ 1;
-            real *Wc = Wb + cur * NX * NP;
-            const real *Wp = Wb + prev * NX * NP;
-            if (dyn) load_F(t);
+            const real Qv = Qn, qv = qn, cv = cn;
+            if (dyn) stash_F(fbuf);
             wave_sync();
             // ---- own F row (W lanes) / F column (H lanes) into registers
 #pragma unroll
             for (int k = 0; k < N; ++k) fa[k] = 0;
-            if (dyn) {
-                if (isW) {
+            if (dyn && (isW || isH)) {
+                const int base = isW ? wr * N : hi, stride = isW ? 1 : N;
 #pragma unroll
-                    for (int k = 0; k < N; ++k) fa[k] = Fs[wr * N + k];
-                } else if (isH) {
+                for (int k = 0; k < N; ++k)
+                    if (isW || k < NX) fa[k] = Fs[base + k * stride];
+                if (isH) {
 #pragma unroll
-                    for (int r = 0; r < NX; ++r) fa[r] = Fs[r * N + hi];
-#pragma unroll
-                    for (int r = 0; r < NXP; ++r) Ft[hi * NXP + r] = r < NX ? fa[r] : real(0);
+                    for (int r4 = 0; r4 < NXP; r4 += 4)
+                        st4(Ft + hi * NXP + r4, fa[r4], r4 + 1 < NX ? fa[r4 + 1] : real(0),
+                            r4 + 2 < NX ? fa[r4 + 2] : real(0), r4 + 3 < NX ? fa[r4 + 3] : real(0));
                 }
             }
+            wave_sync();
+            // ---- prefetch the next stage's inputs (they stay in flight during this stage)
+            if (t + 2 < T) fetch_F(t + 1, fbuf);
+            if (t + 1 < T && isH) { Qn = gQd[(t + 1) * N + hi]; qn = gq[(t + 1) * N + hi]; }
+            if (t + 2 < T && isW) cn = gxnext ? gxnext[(t + 1) * NX + wr] : gc[(t + 1) * NX + wr];
             // ---- dynamics residual r_t and multiplier estimate v = lam + rho r (W lanes)
             if (dyn && isW) {
-                real xn;
-                if (gxnext) {
-                    xn = gxnext[t * NX + wr];
-                } else {
-                    real s = 0;
+                real xn = cv;
+                if (!gxnext) {
 #pragma unroll
-                    for (int k = 0; k < N; ++k) s += fa[k] * zs[t * N + k];
-                    xn = s + gc[t * NX + wr];
+                    for (int k = 0; k < N; ++k) xn = fma_(fa[k], zs[t * N + k], xn);
                 }
                 real r = zs[(t + 1) * N + wr] - xn;
                 req[t * NX + wr] = r;
-                vs[wr] = lams[t * NX + wr] + rho * r;
+                vs[wr] = fma_(rho, r, lams[t * NX + wr]);
             }
             wave_sync();
             // ---- gradient entry and diagonal of H_tt (H lanes), al_utils.py:113-120
             real D = 0;
             if (isH) {
                 real zv = zs[t * N + hi];
-                real Qv = gQd[t * N + hi];
-                real g = Qv * zv + gq[t * N + hi];
+                real g = fma_(Qv, zv, qv);
                 D = Qv;
                 if (hi < NX) {
                     int row = (t == 0) ? (T - 1) * NX + hi : (t - 1) * NX + hi;
-                    g += lams[row] + rho * req[row];
+                    g += fma_(rho, req[row], lams[row]);
                     D += rho;
                 } else {
                     int j = hi - NX;
                     int ru = T * NX + t * 2 * NU + j, rl = ru + NU;
                     real vu = zv - uhi(t, j), vl = -zv + ulo(t, j);
                     real au = vu >= 0 ? real(1) : real(0), al = vl >= 0 ? real(1) : real(0);
-                    D += rho * (au + al);
-                    g += (lams[ru] + rho * (vu > 0 ? vu : real(0))) - (lams[rl] + rho * (vl > 0 ? vl : real(0)));
+                    D = fma_(rho, au + al, D);
+                    g += fma_(rho, vu > 0 ? vu : real(0), lams[ru]) - fma_(rho, vl > 0 ? vl : real(0), lams[rl]);
                 }
                 if (dyn) {
                     real s = 0;
 #pragma unroll
-                    for (int r = 0; r < NX; ++r) s += fa[r] * vs[r];
+                    for (int r4 = 0; r4 < NXP; r4 += 4) {
+                        real v4[4];
+                        ld4(vs + r4, v4);
+#pragma unroll
+                        for (int i = 0; i < 4; ++i)
+                            if (r4 + i < NX) s = fma_(fa[r4 + i], v4[i], s);
+                    }
                     g -= s;
                 }
                 gs[hi] = g;
                 if (g_out) g_out[t * N + hi] = g;
             }
-            // ---- Schur-complement operand rows: W_{t-1} row (H lanes < NX), y_{t-1} (Y lane)
-            if (t > 0 && isH && hi < NX) {
+            // ---- SYRK phase: Hs = rho Ft Ft' - Sb Sb' on 2x2 blocks (lower triangle)
+            if (isBlk) {
+                real a00 = 0, a01 = 0, a10 = 0, a11 = 0;
+                const int i0 = 2 * bi, j0 = 2 * bj;
+                if (dyn) {
 #pragma unroll
-                for (int k = 0; k < N; ++k) bb[k] = Wp[hi * NP + k];
+                    for (int c4 = 0; c4 < NXP; c4 += 4) {
+                        real x0[4], x1[4], y0[4], y1[4];
+                        ld4(Ft + i0 * NXP + c4, x0); ld4(Ft + (i0 + 1) * NXP + c4, x1);
+                        ld4(Ft + j0 * NXP + c4, y0); ld4(Ft + (j0 + 1) * NXP + c4, y1);
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            a00 = fma_(x0[i], y0[i], a00); a01 = fma_(x0[i], y1[i], a01);
+                            a10 = fma_(x1[i], y0[i], a10); a11 = fma_(x1[i], y1[i], a11);
+                        }
+                    }
+                    a00 *= rho; a01 *= rho; a10 *= rho; a11 *= rho;
+                }
+                if (t > 0) {
+#pragma unroll
+                    for (int c4 = 0; c4 < NP; c4 += 4) {
+                        real x0[4], x1[4], y0[4], y1[4];
+                        ld4(Sb + i0 * NP + c4, x0); ld4(Sb + (i0 + 1) * NP + c4, x1);
+                        ld4(Sb + j0 * NP + c4, y0); ld4(Sb + (j0 + 1) * NP + c4, y1);
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            a00 = fma_(-x0[i], y0[i], a00); a01 = fma_(-x0[i], y1[i], a01);
+                            a10 = fma_(-x1[i], y0[i], a10); a11 = fma_(-x1[i], y1[i], a11);
+                        }
+                    }
+                }
+                Hs[i0 * HP + j0] = a00; Hs[i0 * HP + j0 + 1] = a01;
+                Hs[(i0 + 1) * HP + j0] = a10; Hs[(i0 + 1) * HP + j0 + 1] = a11;
             }
             wave_sync();
-            // ---- initial row values
+            // ---- diagonal of H_tt on top of the SYRK result (same lane order: in-order LDS)
+            if (isH) Hs[hi * HP + hi] += D;
+            wave_sync();
+            // ---- initial row values of the panel: H rows / rhs row / identity rows from LDS,
+            //      W rows (-rho F_t) from registers
+            {
+                const int row = isH ? hi : (isU ? RB + ui : N);
+                const real gmul = isY ? real(1) : real(0);
 #pragma unroll
-            for (int k = 0; k < N; ++k) {
-                real v = 0;
-                if (isH) v = (k == hi) ? D : real(0);
-                else if (isW) v = -rho * fa[k];
-                else if (isY) v = -gs[k];
-                else if (isU) v = (k == ui) ? real(1) : real(0);
-                l[k] = v;
+                for (int k4 = 0; k4 < NP; k4 += 4) {
+                    real h4[4], g4[4];
+                    ld4(Hs + row * HP + k4, h4);
+                    ld4(gs + k4, g4);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int k = k4 + i;
+                        if (k < N) l[k] = isW ? -rho * fa[k] : fma_(-gmul, g4[i], h4[i]);
+                    }
+                }
             }
-            // ---- column steps (left-looking)
+            // ---- panel phase (left-looking, operands broadcast from lane j's registers)
 #pragma unroll
             for (int j = 0; j < N; ++j) {
                 real acc = l[j];
-                if (dyn) {
-                    real s = 0;
 #pragma unroll
-                    for (int r = 0; r < NX; ++r) s += fa[r] * Ft[j * NXP + r];
-                    acc += isH ? rho * s : real(0);
-                }
-                if (t > 0 && j < NX) {
-                    real s = 0;
-#pragma unroll
-                    for (int k = 0; k < N; ++k) s += bb[k] * Wp[j * NP + k];
-                    acc -= s;
-                }
-                {
-                    real s = 0;
-#pragma unroll
-                    for (int k = 0; k < j; ++k) s += l[k] * Lw[j * NP + k];
-                    acc -= s;
-                }
+                for (int k = 0; k < j; ++k) acc = fma_(-l[k], team_bcast<G>(l[k], j, team_base), acc);
                 real p = team_bcast<G>(acc, j, team_base);
                 if (!(p > 0) && info == 0) info = t * N + j + 1;
-                real rinv = real(1) / sqrt(p);
-                real v = (j >= jmin && j <= jmax) ? acc * rinv : real(0);
-                l[j] = v;
-                if (isH) Lw[hi * NP + j] = v;
-                else if (isW) Wc[wr * NP + j] = v;
-                wave_sync();
+                // no masking needed: H rows above the diagonal hold unused garbage, identity
+                // rows stay exactly 0 left of their diagonal (X is upper triangular)
+                l[j] = acc * rsqrt_(p);
             }
             // ---- stage results
+            if (isW || isY) {
+                real *dst = isW ? Sb + wr * NP : Sb + N * NP;
+#pragma unroll
+                for (int k4 = 0; k4 < NP; k4 += 4)
+                    st4(dst + k4, l[k4], k4 + 1 < N ? l[k4 + 1] : real(0), k4 + 2 < N ? l[k4 + 2] : real(0),
+                        k4 + 3 < N ? l[k4 + 3] : real(0));
+            }
             if (isY) {
 #pragma unroll
                 for (int k = 0; k < N; ++k) ds[t * N + k] = l[k];
             }
             if (isU) {
-                real *Xr = Xp + (size_t)t * XT + (ui * N - (ui * (ui - 1)) / 2);
+                real *Xr = Xp + (size_t)t * XT + (ui * N - (ui * (ui - 1)) / 2) - ui;
+                // entries left of the diagonal are exact zeros: park them on the diagonal slot,
+                // which the k == ui store then overwrites (stores of one lane stay in order)
 #pragma unroll
-                for (int k = 0; k < N; ++k)
-                    if (k >= ui) Xr[k - ui] = l[k];
+                for (int k = 0; k < N; ++k) Xr[k > ui ? k : ui] = l[k];
             }
-            // Y lane carries y_t as the Schur operand of the next right-hand side
-#pragma unroll
-            for (int k = 0; k < N; ++k) bb[k] = isY ? l[k] : real(0);
             wave_sync();
         }
     }
 
     // Backward sweep: d_t = X_t ( y_t + rho X_t' F_t' dx_{t+1} ), and s = (J d)_eq.
     __device__ void backward_sweep() {
+        real fbuf[FCH];
+        if (T > 1) fetch_F(T - 2, fbuf);
         for (int t = T - 1; t >= 0; --t) {
             const bool dyn = t < T - 1;
             const real *Xt = Xp + (size_t)t * XT;
             real frow[N];
+#pragma unroll
+            for (int k = 0; k < N; ++k) frow[k] = 0;
             if (dyn) {
-                load_F(t);
+                stash_F(fbuf);
                 wave_sync();
+                if (t > 0) fetch_F(t - 1, fbuf);
+                // own F column (H lanes) / own F row (W lanes)
+                if (isH || isW) {
+                    const int base = isW ? wr * N : hi, stride = isW ? 1 : N;
+#pragma unroll
+                    for (int k = 0; k < N; ++k)
+                        if (isW || k < NX) frow[k] = Fs[base + k * stride];
+                }
                 // v = F_t' dx_{t+1}
                 if (isH) {
                     real s = 0;
 #pragma unroll
-                    for (int r = 0; r < NX; ++r) s += Fs[r * N + hi] * ds[(t + 1) * N + r];
+                    for (int r = 0; r < NX; ++r) s = fma_(frow[r], ds[(t + 1) * N + r], s);
                     gs[hi] = s;
-                }
-                if (isW) {
-#pragma unroll
-                    for (int k = 0; k < N; ++k) frow[k] = Fs[wr * N + k];
                 }
                 wave_sync();
             }
@@ -332,26 +451,25 @@ struct Team {
                     real s = 0;
 #pragma unroll
                     for (int i = 0; i < N; ++i)
-                        if (i <= hi) s += Xt[(i * N - (i * (i - 1)) / 2) + (hi - i)] * gs[i];
-                    rhs += rho * s;
+                        s = fma_(keep_if_nonneg(Xt[(i * N - (i * (i - 1)) / 2) + (hi - i)], hi - i), gs[i], s);
+                    rhs = fma_(rho, s, rhs);
                 }
                 rs[hi] = rhs;
             }
             wave_sync();
             // d_i = sum_{j>=i} X[i][j] rhs_j
             if (isH) {
-                const real *Xr = Xt + (hi * N - (hi * (hi - 1)) / 2);
+                const real *Xr = Xt + (hi * N - (hi * (hi - 1)) / 2) - hi;
                 real s = 0;
 #pragma unroll
-                for (int j = 0; j < N; ++j)
-                    if (j >= hi) s += Xr[j - hi] * rs[j];
+                for (int j = 0; j < N; ++j) s = fma_(keep_if_nonneg(Xr[j], j - hi), rs[j], s);
                 ds[t * N + hi] = s;
             }
             wave_sync();
             if (dyn && isW) {
                 real s = 0;
 #pragma unroll
-                for (int k = 0; k < N; ++k) s += frow[k] * ds[t * N + k];
+                for (int k = 0; k < N; ++k) s = fma_(frow[k], ds[t * N + k], s);
                 seq[t * NX + wr] = ds[(t + 1) * N + wr] - s;
             }
         }
@@ -369,19 +487,18 @@ struct Team {
                 load_F(t - 1);
                 // e = X_{t-1} y_{t-1}
                 if (isH) {
-                    const real *Xr = Xq + (hi * N - (hi * (hi - 1)) / 2);
+                    const real *Xr = Xq + (hi * N - (hi * (hi - 1)) / 2) - hi;
                     real s = 0;
 #pragma unroll
-                    for (int j = 0; j < N; ++j)
-                        if (j >= hi) s += Xr[j - hi] * ds[(t - 1) * N + j];
+                    for (int j = 0; j < N; ++j) s = fma_(keep_if_nonneg(Xr[j], j - hi), ds[(t - 1) * N + j], s);
                     gs[hi] = s;
                 }
                 wave_sync();
                 if (isW) {
                     real s = 0;
 #pragma unroll
-                    for (int k = 0; k < N; ++k) s += Fs[wr * N + k] * gs[k];
-                    ds[t * N + wr] += rho * s;
+                    for (int k = 0; k < N; ++k) s = fma_(Fs[wr * N + k], gs[k], s);
+                    ds[t * N + wr] = fma_(rho, s, ds[t * N + wr]);
                 }
                 wave_sync();
             }
@@ -391,7 +508,7 @@ struct Team {
                 real s = 0;
 #pragma unroll
                 for (int i = 0; i < N; ++i)
-                    if (i <= hi) s += Xt[(i * N - (i * (i - 1)) / 2) + (hi - i)] * rs[i];
+                    s = fma_(keep_if_nonneg(Xt[(i * N - (i * (i - 1)) / 2) + (hi - i)], hi - i), rs[i], s);
                 ds[t * N + hi] = s;
             }
             wave_sync();
@@ -421,12 +538,12 @@ struct Team {
             real alpha = 1;
 #pragma unroll
             for (int k = 0; k < K; ++k) {
-                real zk = z + alpha * d;
-                real v = (real(0.5) * Qv * zk + qv) * zk;
+                real zk = fma_(alpha, d, z);
+                real v = fma_(real(0.5) * Qv, zk, qv) * zk;
                 if (isu) {
                     real vu = zk - bu, vl = -zk + bl;
                     real cu = vu > 0 ? vu : real(0), cl = vl > 0 ? vl : real(0);
-                    v += lu * vu + ll * vl + real(0.5) * rho * (cu * cu + cl * cl);
+                    v += fma_(lu, vu, ll * vl) + real(0.5) * rho * fma_(cu, cu, cl * cl);
                 }
                 acc[k] += v;
                 alpha *= real(0.5);
@@ -437,8 +554,8 @@ struct Team {
             real alpha = 1;
 #pragma unroll
             for (int k = 0; k < K; ++k) {
-                real rk = r + alpha * s;
-                acc[k] += lm * rk + real(0.5) * rho * rk * rk;
+                real rk = fma_(alpha, s, r);
+                acc[k] += fma_(real(0.5) * rho * rk, rk, lm * rk);
                 alpha *= real(0.5);
             }
         }
@@ -449,13 +566,13 @@ struct Team {
     // sum r+(z)^2 at the current zs/req (al_utils.py:552 sums this over the batch)
     __device__ real rplus2() {
         real acc = 0;
-        for (int e = li; e < T * NX; e += G) acc += req[e] * req[e];
+        for (int e = li; e < T * NX; e += G) acc = fma_(req[e], req[e], acc);
         for (int e = li; e < T * NU; e += G) {
             int t = e / NU, j = e - t * NU;
             real u = zs[t * N + NX + j];
             real vu = u - uhi(t, j), vl = -u + ulo(t, j);
             real cu = vu > 0 ? vu : real(0), cl = vl > 0 ? vl : real(0);
-            acc += cu * cu + cl * cl;
+            acc += fma_(cu, cu, cl * cl);
         }
         return team_sum<G>(acc);
     }
@@ -463,13 +580,13 @@ struct Team {
     // lam <- lam + rho r ; lam_ineq <- max(0, .)   (AL_mpc.py:316-317)
     __device__ void dual_update() {
         const int neq = T * NX;
-        for (int e = li; e < neq; e += G) lams[e] += rho * req[e];
+        for (int e = li; e < neq; e += G) lams[e] = fma_(rho, req[e], lams[e]);
         for (int e = li; e < T * NU; e += G) {
             int t = e / NU, j = e - t * NU;
             real u = zs[t * N + NX + j];
             int ru = neq + t * 2 * NU + j, rl = ru + NU;
-            real a = lams[ru] + rho * (u - uhi(t, j));
-            real c = lams[rl] + rho * (-u + ulo(t, j));
+            real a = fma_(rho, u - uhi(t, j), lams[ru]);
+            real c = fma_(rho, -u + ulo(t, j), lams[rl]);
             lams[ru] = a < 0 ? real(0) : a;
             lams[rl] = c < 0 ? real(0) : c;
         }

@@ -245,3 +245,34 @@ def test_headline_size_properties():
     o = orc.solve_lin("f32", c(p.Qd), c(p.q), c(p.F), c(p.c), c(p.x0), p.u_lo.cpu().numpy(),
                       p.u_hi.cpu().numpy(), c(p.z0), al_iter=2, exit_mode="fixed")
     assert np.abs(c(z) - o["z"]).max() < 5e-3
+
+
+@pytest.mark.parametrize("nx,nu", [(2, 1), (4, 1), (4, 2), (6, 2), (8, 2), (10, 3), (12, 4), (13, 4), (14, 4)])
+@pytest.mark.parametrize("dtype", ["f32", "f64"])
+def test_every_compiled_dims_vs_oracle(nx, nu, dtype):
+    """Every (nx,nu) instance in the library, ragged batch (B not a multiple of the
+    instances per wavefront), odd horizon. Caught a row-stride overflow for n % 4 == 0."""
+    from deq_mpc_corl_amd import synthetic_problem
+    from deq_mpc_corl_amd.backend import default_backend
+    be = default_backend()
+    dt = TD[dtype]
+    B, T = 9, 7
+    p = synthetic_problem(B, T, nx, nu, seed=5, dtype=dt, device=DEV)
+    M = T * nx + 2 * T * nu
+    z = p.z0.clone()
+    lam = torch.zeros(B, M, dtype=dt, device=DEV)
+    rho = torch.ones(B, dtype=dt, device=DEV)
+    phi = torch.zeros(B, dtype=dt, device=DEV)
+    rn2 = torch.zeros(B, dtype=dt, device=DEV)
+    info = torch.zeros(B, dtype=torch.int32, device=DEV)
+    st = torch.zeros(B, dtype=torch.uint8, device=DEV)
+    be.solve_lin((B, T, nx, nu), p.Qd, p.q, p.F, p.c, p.x0, p.u_lo, p.u_hi, 0, 0, z, lam, rho, phi, rn2,
+                 info, st, al_iter=2, max_newton=4, n_ls=20, flags=3)
+    torch.cuda.synchronize()
+    c = lambda a: a.cpu().numpy()
+    o = orc.solve_lin(dtype, c(p.Qd), c(p.q), c(p.F), c(p.c), c(p.x0), c(p.u_lo), c(p.u_hi), c(p.z0),
+                      al_iter=2, exit_mode="fixed")
+    tol = 1e-10 if dtype == "f64" else 2e-3
+    assert int(info.abs().sum()) == 0
+    assert np.abs(c(z) - o["z"]).max() < tol
+    assert np.abs(c(lam) - o["lam"]).max() < tol * 20
