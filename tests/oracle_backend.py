@@ -1,0 +1,151 @@
+"""TEST-ONLY backend: the solver's backend interface implemented on CPU tensors with
+the oracle's building blocks (oracle/alqp_oracle.c). It lets the host logic of the
+drop-in MPC class (state carry, exit modes, dispatch, sharding) run in the CPU
+container. It is never importable from the product package."""
+import numpy as np
+import torch
+
+from oracle import oracle_py as orc
+
+INIT_MERIT, DUAL_UPDATE, SAVE_FACTOR = 1, 2, 4
+
+
+def _n(t):
+    return t.detach().cpu().numpy()
+
+
+def _sfx(t):
+    return "f64" if t.dtype == torch.float64 else "f32"
+
+
+def _bounds(ulo, uhi, sb, st, B, T, nu):
+    lo, hi = _n(ulo), _n(uhi)
+    if sb == 0 and st == 0:
+        return lo.reshape(nu), hi.reshape(nu)
+    return lo.reshape(B, T, nu), hi.reshape(B, T, nu)
+
+
+class OracleBackend:
+    name = "oracle-test"
+
+    def supported(self, B, T, nx, nu, dtype):
+        return True
+
+    def solve_lin(self, dims, Qd, q, F, c, x0, ulo, uhi, sb_u, st_u, z, lam, rho, phi, rnorm2=None,
+                  info=None, status=None, factor=None, al_iter=2, max_newton=4, n_ls=20, flags=3,
+                  rho_scale=10.0, trace=None):
+        B, T, nx, nu = dims
+        s = _sfx(z)
+        npdt = np.float64 if s == "f64" else np.float32
+        lo, hi = _bounds(ulo, uhi, sb_u, st_u, B, T, nu)
+        Qd_, q_, F_, c_, x0_ = _n(Qd), _n(q), _n(F), _n(c), _n(x0)
+        zz, ll, rr, ph = _n(z).copy(), _n(lam).copy(), _n(rho).copy(), _n(phi).copy()
+
+        def xnext(v):
+            return (np.einsum("btij,btj->bti", F_, v[:, :-1]) + c_).astype(npdt)
+
+        L = None
+        for _ in range(al_iter):
+            if flags & INIT_MERIT:
+                ph, _ = orc.merit(s, zz, xnext(zz), x0_, ll, rr, Qd_, q_, lo, hi)
+            for _ in range(max_newton):
+                g, Hd, Hs = orc.grad_hess(s, zz, xnext(zz), F_, x0_, ll, rr, Qd_, q_, lo, hi)
+                d, _, L, _ = orc.newton_dir(s, g, Hd, Hs, nx, want_factor=True)
+                phis = []
+                for k in range(n_ls):
+                    zc = (zz + npdt(2.0 ** -k) * d).astype(npdt)
+                    phis.append(orc.merit(s, zc, xnext(zc), x0_, ll, rr, Qd_, q_, lo, hi)[0])
+                kk, acc, pm = orc.linesearch_pick(s, np.stack(phis), ph)
+                alpha = np.where(acc > 0, 2.0 ** -kk.astype(np.float64), 0.0).astype(npdt)
+                zz = (zz + alpha[:, None, None] * d).astype(npdt)
+                ph = pm
+            if flags & DUAL_UPDATE:
+                ll, rr = orc.dual_update(s, zz, xnext(zz), x0_, lo, hi, ll, rr)
+                if rho_scale != 10.0:
+                    rr = rr / 10.0 * rho_scale
+        _, rp2 = orc.merit(s, zz, xnext(zz), x0_, ll, rr, Qd_, q_, lo, hi)
+        z.copy_(torch.from_numpy(zz)); lam.copy_(torch.from_numpy(ll)); rho.copy_(torch.from_numpy(rr))
+        phi.copy_(torch.from_numpy(ph))
+        if rnorm2 is not None:
+            rnorm2.copy_(torch.from_numpy(rp2))
+        if info is not None:
+            info.zero_()
+        if status is not None:
+            status.copy_(torch.from_numpy(np.isfinite(zz).all(axis=(1, 2)).astype(np.uint8)))
+        if factor is not None and (flags & SAVE_FACTOR) and L is not None:
+            factor.copy_(torch.from_numpy(self._pack_X(L)))
+
+    @staticmethod
+    def _pack_X(L):
+        """L[B,T,n,n] -> packed upper rows of X = L^{-T} (the device factor layout)."""
+        B, T, n, _ = L.shape
+        X = np.linalg.inv(L.astype(np.float64)).transpose(0, 1, 3, 2)
+        out = np.zeros((B, T, n * (n + 1) // 2), L.dtype)
+        off = 0
+        for i in range(n):
+            out[..., off:off + n - i] = X[..., i, i:]
+            off += n - i
+        return out
+
+    @staticmethod
+    def _unpack_L(fac, n):
+        B, T, _ = fac.shape
+        X = np.zeros((B, T, n, n), np.float64)
+        off = 0
+        for i in range(n):
+            X[..., i, i:] = fac[..., off:off + n - i]
+            off += n - i
+        return np.linalg.inv(X.transpose(0, 1, 3, 2))
+
+    def newton_step(self, dims, z, xnext, F, x0, lam, rho, Qd, q, ulo, uhi, sb_u, st_u, d_out, g_out=None,
+                    factor=None, info=None):
+        B, T, nx, nu = dims
+        s = _sfx(z)
+        lo, hi = _bounds(ulo, uhi, sb_u, st_u, B, T, nu)
+        g, Hd, Hs = orc.grad_hess(s, _n(z), _n(xnext), _n(F), _n(x0), _n(lam), _n(rho), _n(Qd), _n(q), lo, hi)
+        d, inf, L, _ = orc.newton_dir(s, g, Hd, Hs, nx, want_factor=True)
+        d_out.copy_(torch.from_numpy(d))
+        if g_out is not None:
+            g_out.copy_(torch.from_numpy(g))
+        if factor is not None:
+            factor.copy_(torch.from_numpy(self._pack_X(L)))
+        if info is not None:
+            info.copy_(torch.from_numpy(inf))
+
+    def merit(self, dims, K, zc, xnext, x0, lam, rho, Qd, q, ulo, uhi, sb_u, st_u, phi, rnorm2=None):
+        B, T, nx, nu = dims
+        s = _sfx(zc)
+        lo, hi = _bounds(ulo, uhi, sb_u, st_u, B, T, nu)
+        zc_, xn_ = _n(zc).reshape(K, B, T, nx + nu), _n(xnext).reshape(K, B, T - 1, nx)
+        for k in range(K):
+            p, r2 = orc.merit(s, zc_[k], xn_[k], _n(x0), _n(lam), _n(rho), _n(Qd), _n(q), lo, hi)
+            phi.view(K, B)[k].copy_(torch.from_numpy(p))
+            if rnorm2 is not None:
+                rnorm2.view(K, B)[k].copy_(torch.from_numpy(r2))
+
+    def linesearch_pick(self, dims, n_ls, phi, phi_prev, d, z, k_out=None, accept_out=None):
+        s = _sfx(z)
+        kk, acc, pm = orc.linesearch_pick(s, _n(phi), _n(phi_prev))
+        alpha = torch.from_numpy(np.where(acc > 0, 2.0 ** -kk.astype(np.float64), 0.0)).to(z.dtype)
+        z.add_(alpha[:, None, None] * d)
+        phi_prev.copy_(torch.from_numpy(pm))
+        if k_out is not None:
+            k_out.copy_(torch.from_numpy(kk))
+        if accept_out is not None:
+            accept_out.copy_(torch.from_numpy(acc))
+
+    def dual_update(self, dims, z, xnext, x0, ulo, uhi, sb_u, st_u, lam, rho, rho_scale=10.0):
+        B, T, nx, nu = dims
+        s = _sfx(z)
+        lo, hi = _bounds(ulo, uhi, sb_u, st_u, B, T, nu)
+        ll, rr = orc.dual_update(s, _n(z), _n(xnext), _n(x0), lo, hi, _n(lam), _n(rho))
+        lam.copy_(torch.from_numpy(ll))
+        rho.copy_(torch.from_numpy(rr))
+
+    def backward(self, dims, factor, F, rho, z_final, gbar, q_grad, Qd_grad):
+        B, T, nx, nu = dims
+        s = _sfx(gbar)
+        L = self._unpack_L(_n(factor), nx + nu).astype(_n(gbar).dtype)
+        qg, Qg = orc.backward(s, L, _n(F), _n(rho), _n(z_final), _n(gbar))
+        q_grad.copy_(torch.from_numpy(qg))
+        Qd_grad.copy_(torch.from_numpy(Qg))

@@ -1,0 +1,74 @@
+"""CPU checks of the C-ABI boundary: the shared library loads without a GPU, exports
+every symbol include/mi_alqp.h declares, and rejects bad input before any launch."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    txt = open(os.path.join(ROOT, "include", "mi_alqp.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(alqp_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_library_exports_every_declared_symbol():
+    from deq_mpc_corl_amd import _lib
+    lib = _lib.load()
+    syms = declared_symbols()
+    assert len(syms) >= 16
+    for s in syms:
+        assert hasattr(lib, s), s
+    assert sorted(syms) == sorted(_lib.EXPORTED_SYMBOLS)
+    assert lib.alqp_abi_version() == _lib.ABI_VERSION
+
+
+def test_supported_dims_and_lds_budget():
+    from deq_mpc_corl_amd import _lib
+    lib = _lib.load()
+    q = lambda *d: (lib.alqp_supported(C.byref(_lib.AlqpDims(*d)), 0), lib.alqp_supported(C.byref(_lib.AlqpDims(*d)), 1))
+    assert q(16384, 20, 13, 4) == (1, 1)
+    assert q(128, 5, 2, 1) == (1, 1)
+    assert q(8192, 10, 8, 2) == (1, 1)
+    assert q(65536, 50, 13, 4) == (1, 1)
+    assert q(4, 20, 7, 3) == (0, 0)            # not instantiated
+    assert q(4, 1, 13, 4) == (0, 0)            # T < 2
+    assert q(4, 400, 13, 4) == (0, 0)          # horizon does not fit 160 KiB of LDS
+    d = _lib.AlqpDims(1, 20, 13, 4)
+    assert 0 < lib.alqp_lds_bytes(C.byref(d), 0) <= 160 * 1024
+    assert lib.alqp_qps_per_wave(C.byref(d), 0) == 1
+    assert lib.alqp_qps_per_wave(C.byref(_lib.AlqpDims(1, 5, 2, 1)), 0) == 4
+
+
+def test_bad_arguments_are_rejected_without_a_launch():
+    from deq_mpc_corl_amd import _lib
+    lib = _lib.load()
+    d = _lib.AlqpDims(4, 20, 13, 4)
+    p = _lib.AlqpParams(2, 4, 20, 3, 10.0)
+    rc = lib.alqp_solve_lin_f32(C.byref(d), C.byref(p), *([None] * 7), 0, 0, *([None] * 8), None, None)
+    assert rc == -1
+    rc = lib.alqp_backward_f64(C.byref(d), *([None] * 8))
+    assert rc == -1
+    fake = C.c_void_p(16)
+    bad = _lib.AlqpParams(2, 4, 21, 3, 10.0)  # n_ls > 20
+    rc = lib.alqp_solve_lin_f32(C.byref(d), C.byref(bad), *([fake] * 7), 0, 0, *([fake] * 8), None, None)
+    assert rc == -1
+    d2 = _lib.AlqpDims(4, 20, 7, 3)
+
+
+def test_product_path_fails_loudly_on_cpu_tensors():
+    """No CPU fallback: CPU tensors reach the HIP backend and raise."""
+    import torch
+    from deq_mpc_corl_amd import MPC, AffineDynamics, QuadCost, synthetic_problem
+    p = synthetic_problem(4, 5, 2, 1, dtype=torch.float32)
+    mpc = MPC(2, 1, 5, u_lower=p.u_lo, u_upper=p.u_hi, n_batch=4, dtype=torch.float32, exit_mode="fixed")
+    with pytest.raises(RuntimeError, match="reinitialize"):
+        mpc(p.x0, QuadCost(torch.diag_embed(p.Qd), p.q, torch.zeros(4, 5)), None, None)
+    mpc.reinitialize(p.x0, None)
+    dyn = AffineDynamics(p.F, p.c)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        mpc(p.x0, QuadCost(torch.diag_embed(p.Qd), p.q, torch.zeros(4, 5)), dyn, dyn.jac,
+            x_init=p.z0[..., :2], u_init=p.z0[..., 2:])

@@ -1,0 +1,98 @@
+"""N > 1 path on CPU: world_size-2 gloo processes, each owning a slab of the batch.
+The TEST-ONLY oracle backend stands in for the GPU; what is tested is the sharding
+logic: slabs, the 8-byte all-reduce that keeps the batch-global exit decision of the
+reference, and the all-gather of the solution."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from tests import golden_util as gu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, name, exit_mode, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    from deq_mpc_corl_amd import AffineDynamics, QuadCost
+    from deq_mpc_corl_amd.sharding import gather_batch, make_sharded_mpc, shard
+    from tests.oracle_backend import OracleBackend
+    g = gu.load(name)
+    dt = torch.float64
+    B, T, nx, nu = g["B"], g["T"], g["nx"], g["nu"]
+    t = lambda a: shard(torch.as_tensor(np.ascontiguousarray(a)).to(dt), rank, world)
+    mpc = make_sharded_mpc(nx, nu, T, torch.as_tensor(g["u_lo"]).to(dt), torch.as_tensor(g["u_hi"]).to(dt),
+                           B, rank, world, dtype=dt, exit_mode=exit_mode, backend=OracleBackend())
+    x0 = t(g["x0"])
+    mpc.reinitialize(x0, None)
+    mpc.al_iter = g["al_iter"]
+    dyn = AffineDynamics(t(g["F"]), t(g["c"]))
+    Bl = x0.shape[0]
+    cost = QuadCost(torch.diag_embed(t(g["Qd"])), t(g["q"]), torch.zeros(Bl, T, dtype=dt))
+    z0 = t(g["z0"])
+    x, u, _ = mpc(x0, cost, dyn, dyn.jac, x_init=z0[..., :nx].clone(), u_init=z0[..., nx:].clone())
+    xg = gather_batch(x, B)
+    ug = gather_batch(u, B)
+    if rank == 0:
+        np.savez(os.path.join(out_dir, "out.npz"), x=xg.numpy(), u=ug.numpy(),
+                 npa=np.array(mpc.last_newton_per_al))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("name,B_note", [("pend_f64_al2", "even slabs"), ("pend_active_f64_al6", "even slabs")])
+def test_sharded_reference_exit_matches_unsharded_reference(name, B_note, tmp_path):
+    """pend_* goldens are the cases where the reference's batch-global early exit fires
+    ([4,3] Newton steps): a rank deciding on its own slab would take a different number
+    of steps; with the all-reduce both ranks reproduce the reference exactly."""
+    g = gu.load(name)
+    mp.spawn(_worker, args=(2, _free_port(), name, "reference", str(tmp_path)), nprocs=2, join=True)
+    out = np.load(tmp_path / "out.npz")
+    assert list(out["npa"]) == list(g["newton_per_al"])
+    assert np.abs(out["x"] - g["x"]).max() < 2e-5
+    assert np.abs(out["u"] - g["u"]).max() < 2e-5
+
+
+def test_sharded_fixed_mode_equals_unsharded_fixed_mode(tmp_path):
+    """exit_mode='fixed' takes no batch-global decision: slabs need no collective and the
+    gathered result equals the single-process result bit for bit."""
+    from deq_mpc_corl_amd import MPC, AffineDynamics, QuadCost
+    from tests.oracle_backend import OracleBackend
+    name = "cart_f64_al2"
+    g = gu.load(name)
+    mp.spawn(_worker, args=(2, _free_port(), name, "fixed", str(tmp_path)), nprocs=2, join=True)
+    out = np.load(tmp_path / "out.npz")
+    dt = torch.float64
+    t = lambda a: torch.as_tensor(np.ascontiguousarray(a)).to(dt)
+    B, T, nx, nu = g["B"], g["T"], g["nx"], g["nu"]
+    mpc = MPC(nx, nu, T, u_lower=t(g["u_lo"]), u_upper=t(g["u_hi"]), n_batch=B, dtype=dt, exit_mode="fixed",
+              backend=OracleBackend())
+    mpc.reinitialize(t(g["x0"]), None)
+    dyn = AffineDynamics(t(g["F"]), t(g["c"]))
+    z0 = t(g["z0"])
+    x, u, _ = mpc(t(g["x0"]), QuadCost(torch.diag_embed(t(g["Qd"])), t(g["q"]), torch.zeros(B, T, dtype=dt)),
+                  dyn, dyn.jac, x_init=z0[..., :nx].clone(), u_init=z0[..., nx:].clone())
+    assert np.array_equal(out["x"], x.numpy()) and np.array_equal(out["u"], u.numpy())
+
+
+def test_shard_range_covers_batch():
+    from deq_mpc_corl_amd.sharding import shard_range
+    for B in (1, 7, 8, 65536, 16385):
+        for w in (1, 2, 3, 8):
+            rs = [shard_range(B, r, w) for r in range(w)]
+            assert rs[0][0] == 0 and rs[-1][1] == B
+            assert all(rs[i][1] == rs[i + 1][0] for i in range(w - 1))
+            assert max(h - l for l, h in rs) - min(h - l for l, h in rs) <= 1
