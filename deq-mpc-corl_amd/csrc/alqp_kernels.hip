@@ -56,7 +56,7 @@ __device__ inline unsigned opaque_zero() {
 
 // ---- fused LinDx solve -------------------------------------------------------------
 template <typename real, int NX, int NU, bool TRACE>
-__global__ __launch_bounds__(64) void k_solve_lin(SolveArgs<real> a, TraceArgs<real> tr) {
+__global__ __launch_bounds__(64, 2) void k_solve_lin(SolveArgs<real> a, TraceArgs<real> tr) {
     using C = Cfg<real, NX, NU>;
     constexpr int G = C::G, N = C::N;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -79,9 +79,8 @@ __global__ __launch_bounds__(64) void k_solve_lin(SolveArgs<real> a, TraceArgs<r
     tm.st_u = a.st_u;
 
     real *gz = a.z + (size_t)b * T * N;
-    real *glam = a.lam + (size_t)b * M;
+    tm.lams = a.lam + (size_t)b * M;  // multipliers stay in global memory (L2), updated in place
     for (int e = li; e < T * N; e += G) tm.zs[e] = gz[e];
-    for (int e = li; e < M; e += G) tm.lams[e] = glam[e];
     tm.rho = a.rho[b];
     real phi_prev = a.phi[b];
     wave_sync();
@@ -135,7 +134,7 @@ __global__ __launch_bounds__(64) void k_solve_lin(SolveArgs<real> a, TraceArgs<r
             phi_prev = best;  // merit <- new_merit even when rejected (al_utils.py:569)
         }
         if (a.flags & ALQP_DUAL_UPDATE) {
-            tm.dual_update();
+            if (active) tm.dual_update();  // in-place on global lam: padding teams must not touch it
             tm.rho *= a.rho_scale;
         }
     }
@@ -149,7 +148,6 @@ __global__ __launch_bounds__(64) void k_solve_lin(SolveArgs<real> a, TraceArgs<r
     bad = team_or<G>(bad);
     if (active) {
         for (int e = li; e < T * N; e += G) gz[e] = tm.zs[e];
-        for (int e = li; e < M; e += G) glam[e] = tm.lams[e];
         if ((a.flags & ALQP_SAVE_FACTOR) && a.factor) {
             real *gf = a.factor + (size_t)b * T * C::XT;
             for (int e = li; e < T * C::XT; e += G) gf[e] = tm.Xp[e];
@@ -189,9 +187,8 @@ __global__ __launch_bounds__(64) void k_newton_step(StepArgs<real> a) {
     tm.st_u = a.st_u;
     tm.gxnext = a.xnext + (size_t)b * (T - 1) * NX;
     const real *gz = a.z + (size_t)b * T * N;
-    const real *glam = a.lam + (size_t)b * M;
+    tm.lams = const_cast<real *>(a.lam) + (size_t)b * M;  // read-only here
     for (int e = li; e < T * N; e += G) tm.zs[e] = gz[e];
-    for (int e = li; e < M; e += G) tm.lams[e] = glam[e];
     tm.rho = a.rho[b];
     wave_sync();
     tm.forward_sweep((active && a.g_out) ? a.g_out + (size_t)b * T * N : nullptr);

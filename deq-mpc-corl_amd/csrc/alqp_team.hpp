@@ -51,18 +51,22 @@ struct Cfg {
     static constexpr int HP = pad4(RB);         // row stride of Hs: the 2x2 blocks span RB columns
     static_assert(NBLK <= G, "SYRK blocks must fit the team");
     // per-team LDS scratch, offsets in reals (all multiples of 4 -> 16-byte aligned)
-    static constexpr int oFs = 0;                      // raw F_t                    [NX*N]
-    static constexpr int oFt = oFs + pad4(NX * N);     // [F_t' ; 0]                 [RB][NXP]
-    static constexpr int oSb = oFt + RB * NXP;         // [W_{t-1} ; 0 ; y_{t-1}']   [RB][NP]
-    static constexpr int oHs = oSb + RB * NP;          // SYRK result, then identity [RB+N][HP]
-    static constexpr int oVs = oHs + (RB + N) * HP;    // nx-vector                  [NXP]
+    static constexpr int oFt = 0;                      // [F_t' ; 0]                 [RB][NXP]
+    static constexpr int oSb = oFt + RB * NXP;         // [W_{t-1} ; 0 ; y_{t-1}']   [RB][NP]  (also s_eq)
+    static constexpr int oHs = oSb + RB * NP;          // SYRK result                [RB][HP]  (also raw F_t)
+    static constexpr int oVs = oHs + RB * HP;          // nx-vector                  [NXP]
     static constexpr int oGs = oVs + NXP;              // n-vector                   [NP]
     static constexpr int oRs = oGs + NP;               // n-vector                   [NP]
     static constexpr int SCRATCH = oRs + NP;
+    static_assert(pad4(NX * N) <= RB * HP, "raw F_t is staged in the Hs region");
     __host__ __device__ static constexpr int M(int T) { return T * NX + 2 * T * NU; }
-    // persistent arrays: z, d (y), r_eq, s_eq = (J d)_eq, lam, X
+    // s_eq = (J d)_eq lives in the Sb region between the backward sweep and the line
+    // search when it fits (short horizons), else in its own array
+    __host__ __device__ static constexpr bool seq_in_scratch(int T) { return T * NX <= RB * NP; }
+    // persistent arrays: z, d (y), r_eq, [s_eq], X      (lam stays in global memory / L2)
     __host__ __device__ static constexpr int team_words(int T) {
-        return SCRATCH + 2 * pad4(T * N) + 2 * pad4(T * NX) + pad4(M(T)) + pad4(T * XT);
+        return SCRATCH + 2 * pad4(T * N) + pad4(T * NX) + (seq_in_scratch(T) ? 0 : pad4(T * NX)) +
+               pad4(T * XT);
     }
 };
 
@@ -72,6 +76,10 @@ __device__ inline float fma_(float a, float b, float c) { return __builtin_fmaf(
 __device__ inline double fma_(double a, double b, double c) { return __builtin_fma(a, b, c); }
 
 // 1/sqrt(p): fp32 uses v_rsq_f32 (<= 1 ulp), fp64 the correctly rounded sequence
+__device__ inline float fabs_(float a) { return __builtin_fabsf(a); }
+__device__ inline double fabs_(double a) { return __builtin_fabs(a); }
+__device__ inline float fmax_(float a, float b) { return __builtin_fmaxf(a, b); }
+__device__ inline double fmax_(double a, double b) { return __builtin_fmax(a, b); }
 __device__ inline float rsqrt_(float p) { return __builtin_amdgcn_rsqf(p); }
 __device__ inline double rsqrt_(double p) { return 1.0 / __builtin_sqrt(p); }
 
@@ -148,7 +156,9 @@ struct Team {
 
     // LDS
     real *Fs, *Ft, *Sb, *Hs, *vs, *gs, *rs;
-    real *zs, *ds, *req, *seq, *lams, *Xp;
+    real *zs, *ds, *req, *seq, *Xp;
+    real *lams;  // GLOBAL memory (this instance's multipliers, updated in place)
+    real ufl;    // float(ui) for identity rows, -100 elsewhere
     // identity
     int li, team_base, T, b;
     bool isH, isW, isY, isU, isBlk;
@@ -163,18 +173,20 @@ struct Team {
     // get scalarised by the compiler into ds_read + v_readfirstlane + SGPR-spill chains.
     __device__ void init(real *lds_team, int lane_in_team, int team_base_, int T_, int b_) {
         li = lane_in_team; team_base = team_base_; T = T_; b = b_;
-        Fs = lds_team + C::oFs; Ft = lds_team + C::oFt; Sb = lds_team + C::oSb;
-        Hs = lds_team + C::oHs; vs = lds_team + C::oVs; gs = lds_team + C::oGs; rs = lds_team + C::oRs;
+        Ft = lds_team + C::oFt; Sb = lds_team + C::oSb; Hs = lds_team + C::oHs;
+        Fs = Hs;
+        vs = lds_team + C::oVs; gs = lds_team + C::oGs; rs = lds_team + C::oRs;
         real *p = lds_team + C::SCRATCH;
         zs = p; p += pad4(T * N);
         ds = p; p += pad4(T * N);
         req = p; p += pad4(T * NX);
-        seq = p; p += pad4(T * NX);
-        lams = p; p += pad4(C::M(T));
+        if (C::seq_in_scratch(T)) seq = Sb; else { seq = p; p += pad4(T * NX); }
         Xp = p;
+        lams = nullptr;
         isH = li < N; isW = li >= N && li < N + NX; isY = li == N + NX;
         isU = li > N + NX && li < C::NROWS;
         hi = isH ? li : 0; wr = isW ? li - N : 0; ui = isU ? li - (N + NX + 1) : 0;
+        ufl = isU ? real(ui) : real(-100);
         // SYRK block owned by this lane: lower-triangular enumeration (bi >= bj)
         isBlk = li < C::NBLK;
         bi = 0; bj = 0;
@@ -189,7 +201,6 @@ struct Team {
         for (int e = li; e < RB * NXP; e += G) Ft[e] = 0;
         for (int e = li; e < RB * NP; e += G) Sb[e] = 0;
         for (int e = li; e < RB * HP; e += G) Hs[e] = 0;
-        for (int e = li; e < N * HP; e += G) Hs[RB * HP + e] = (e / HP == e % HP) ? real(1) : real(0);
         for (int e = li; e < NXP; e += G) vs[e] = 0;
         for (int e = li; e < NP; e += G) gs[e] = 0;
         wave_sync();
@@ -254,9 +265,19 @@ struct Team {
         fetch_F(0, fbuf);
         real Qn = isH ? gQd[hi] : real(0), qn = isH ? gq[hi] : real(0);
         real cn = isW ? (gxnext ? gxnext[wr] : gc[wr]) : real(0);
+        // multipliers this lane needs at stage t (global memory, prefetched a stage ahead):
+        //   x rows: lam of the eq row that pins x_t (init row for t = 0, dynamics row t-1)
+        //   u rows: upper / lower bound multipliers;  W lanes: lam of dynamics row t
+        const bool isHx = isH && hi < NX, isHu = isH && hi >= NX;
+        real lan = 0, lbn = 0;
+        if (isHx) lan = lams[(T - 1) * NX + hi];
+        if (isHu) { lan = lams[T * NX + (hi - NX)]; lbn = lams[T * NX + NU + (hi - NX)]; }
+        if (isW) lan = lams[wr];
+        // Sb may hold s_eq of the previous Newton step: restore its constant zero rows
+        for (int e = li; e < RB * NP; e += G) Sb[e] = 0;
         for (int t = 0; t < T; ++t) {
             const bool dyn = t < T - 1;
-            const real Qv = Qn, qv = qn, cv = cn;
+            const real Qv = Qn, qv = qn, cv = cn, la = lan, lb = lbn;
             if (dyn) stash_F(fbuf);
             wave_sync();
             // ---- own F row (W lanes) / F column (H lanes) into registers
@@ -278,7 +299,17 @@ struct Team {
             // ---- prefetch the next stage's inputs (they stay in flight during this stage)
             if (t + 2 < T) fetch_F(t + 1, fbuf);
             if (t + 1 < T && isH) { Qn = gQd[(t + 1) * N + hi]; qn = gq[(t + 1) * N + hi]; }
-            if (t + 2 < T && isW) cn = gxnext ? gxnext[(t + 1) * NX + wr] : gc[(t + 1) * NX + wr];
+            if (t + 2 < T && isW) {
+                cn = gxnext ? gxnext[(t + 1) * NX + wr] : gc[(t + 1) * NX + wr];
+                lan = lams[(t + 1) * NX + wr];
+            }
+            if (t + 1 < T) {
+                if (isHx) lan = lams[t * NX + hi];
+                if (isHu) {
+                    lan = lams[T * NX + (t + 1) * 2 * NU + (hi - NX)];
+                    lbn = lams[T * NX + (t + 1) * 2 * NU + NU + (hi - NX)];
+                }
+            }
             // ---- dynamics residual r_t and multiplier estimate v = lam + rho r (W lanes)
             if (dyn && isW) {
                 real xn = cv;
@@ -288,7 +319,7 @@ struct Team {
                 }
                 real r = zs[(t + 1) * N + wr] - xn;
                 req[t * NX + wr] = r;
-                vs[wr] = fma_(rho, r, lams[t * NX + wr]);
+                vs[wr] = fma_(rho, r, la);
             }
             wave_sync();
             // ---- gradient entry and diagonal of H_tt (H lanes), al_utils.py:113-120
@@ -299,15 +330,14 @@ struct Team {
                 D = Qv;
                 if (hi < NX) {
                     int row = (t == 0) ? (T - 1) * NX + hi : (t - 1) * NX + hi;
-                    g += fma_(rho, req[row], lams[row]);
+                    g += fma_(rho, req[row], la);
                     D += rho;
                 } else {
                     int j = hi - NX;
-                    int ru = T * NX + t * 2 * NU + j, rl = ru + NU;
                     real vu = zv - uhi(t, j), vl = -zv + ulo(t, j);
                     real au = vu >= 0 ? real(1) : real(0), al = vl >= 0 ? real(1) : real(0);
                     D = fma_(rho, au + al, D);
-                    g += fma_(rho, vu > 0 ? vu : real(0), lams[ru]) - fma_(rho, vl > 0 ? vl : real(0), lams[rl]);
+                    g += fma_(rho, vu > 0 ? vu : real(0), la) - fma_(rho, vl > 0 ? vl : real(0), lb);
                 }
                 if (dyn) {
                     real s = 0;
@@ -362,11 +392,11 @@ struct Team {
             // ---- diagonal of H_tt on top of the SYRK result (same lane order: in-order LDS)
             if (isH) Hs[hi * HP + hi] += D;
             wave_sync();
-            // ---- initial row values of the panel: H rows / rhs row / identity rows from LDS,
-            //      W rows (-rho F_t) from registers
+            // ---- initial row values of the panel: H rows / rhs row from LDS, W rows (-rho F_t)
+            //      from registers, identity rows start at 0 and get their 1 at column ui
             {
-                const int row = isH ? hi : (isU ? RB + ui : N);
-                const real gmul = isY ? real(1) : real(0);
+                const int row = isH ? hi : N;
+                const real gmul = isY ? real(1) : real(0), hmul = isU ? real(0) : real(1);
 #pragma unroll
                 for (int k4 = 0; k4 < NP; k4 += 4) {
                     real h4[4], g4[4];
@@ -375,14 +405,16 @@ struct Team {
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
                         const int k = k4 + i;
-                        if (k < N) l[k] = isW ? -rho * fa[k] : fma_(-gmul, g4[i], h4[i]);
+                        if (k < N) l[k] = isW ? -rho * fa[k] : fma_(-gmul, g4[i], hmul * h4[i]);
                     }
                 }
             }
             // ---- panel phase (left-looking, operands broadcast from lane j's registers)
 #pragma unroll
             for (int j = 0; j < N; ++j) {
-                real acc = l[j];
+                // identity entry: 1 on lane (identity row j), 0 elsewhere, as arithmetic on a
+                // per-lane float (a compare per j would be hoisted into 2 SGPRs each)
+                real acc = l[j] + fmax_(real(0), real(1) - fabs_(ufl - real(j)));
 #pragma unroll
                 for (int k = 0; k < j; ++k) acc = fma_(-l[k], team_bcast<G>(l[k], j, team_base), acc);
                 real p = team_bcast<G>(acc, j, team_base);
