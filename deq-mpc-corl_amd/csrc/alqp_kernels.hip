@@ -106,13 +106,42 @@ __global__ __launch_bounds__(64, 2) void k_solve_lin(SolveArgs<real> a, TraceArg
             }
             real ph[20];
             tm.template merit_candidates<20>(ph, false);
+            // first argmin, a NaN wins like torch.min (al_utils.py:634)
             int kbest = 0;
             real best = ph[0];
+            if (a.n_ls == 20) {
 #pragma unroll
-            for (int k = 1; k < 20; ++k) {
-                if (k < a.n_ls && !(best != best) && (ph[k] != ph[k] || ph[k] < best)) {
-                    best = ph[k];
-                    kbest = k;
+                for (int k = 1; k < 20; ++k) {
+                    if (!(best != best) && (ph[k] != ph[k] || ph[k] < best)) {
+                        best = ph[k];
+                        kbest = k;
+                    }
+                }
+            } else if constexpr (C::RB * C::NXP >= 20) {
+                // fewer candidates (tests): go through LDS (the Ft region is free here)
+                // instead of 20 hoisted lane masks
+                if (li == 0) {
+#pragma unroll
+                    for (int k = 0; k < 20; ++k) tm.Ft[k] = ph[k];
+                }
+                wave_sync();
+                for (int k = 1; k < a.n_ls; ++k) {
+                    real v = tm.Ft[k];
+                    if (!(best != best) && (v != v || v < best)) {
+                        best = v;
+                        kbest = k;
+                    }
+                }
+                wave_sync();
+                if (li < 20) tm.Ft[li] = 0;  // restore the constant zeros of the SYRK operand
+                wave_sync();
+            } else {
+#pragma unroll
+                for (int k = 1; k < 20; ++k) {
+                    if (k < a.n_ls && !(best != best) && (ph[k] != ph[k] || ph[k] < best)) {
+                        best = ph[k];
+                        kbest = k;
+                    }
                 }
             }
             const bool acc = best < phi_prev;

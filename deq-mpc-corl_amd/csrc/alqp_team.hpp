@@ -548,51 +548,57 @@ struct Team {
     }
 
     // Merit of K candidates z + alpha_k d (alpha_k = 2^-k), al_utils.py:73-77.
-    // Equality residuals move linearly along d: r + alpha s (affine dynamics).
-    // Every lane returns all K sums. K = 1 evaluates the merit at z itself.
+    // Along the Newton direction the cost and the equality terms are exactly quadratic in
+    // alpha (affine dynamics: r + alpha s), so they are accumulated once as three sums
+    //   phi(alpha) = c0 + alpha c1 + alpha^2 c2 + bound terms(alpha)
+    // and only the clamped bound terms are evaluated per candidate. Every lane returns
+    // all K values. K = 1 with at_z evaluates the merit at z itself.
     template <int K>
     __device__ void merit_candidates(real (&phi)[K], bool at_z) {
+        const int neq = T * NX;
+        real c0 = 0, c1 = 0, c2 = 0;
+        for (int e = li; e < T * N; e += G) {
+            real z = zs[e], d = at_z ? real(0) : ds[e];
+            real Qv = gQd[e], qv = gq[e];
+            real gz = fma_(Qv, z, qv);
+            c0 = fma_(fma_(real(0.5) * Qv, z, qv), z, c0);
+            c1 = fma_(gz, d, c1);
+            c2 = fma_(real(0.5) * Qv * d, d, c2);
+        }
+        for (int e = li; e < neq; e += G) {
+            real r = req[e], sv = at_z ? real(0) : seq[e], lm = lams[e];
+            c0 = fma_(fma_(real(0.5) * rho, r, lm), r, c0);
+            c1 = fma_(fma_(rho, r, lm), sv, c1);
+            c2 = fma_(real(0.5) * rho * sv, sv, c2);
+        }
         real acc[K];
 #pragma unroll
         for (int k = 0; k < K; ++k) acc[k] = 0;
-        const int neq = T * NX;
-        for (int e = li; e < T * N; e += G) {
-            int t = e / N, j = e - t * N;
-            real z = zs[e], d = at_z ? real(0) : ds[e];
-            real Qv = gQd[e], qv = gq[e];
-            bool isu = j >= NX;
-            real lu = 0, ll = 0, bu = 0, bl = 0;
-            if (isu) {
-                int ru = neq + t * 2 * NU + (j - NX);
-                lu = lams[ru]; ll = lams[ru + NU];
-                bu = uhi(t, j - NX); bl = ulo(t, j - NX);
-            }
+        for (int e = li; e < T * NU; e += G) {
+            int t = e / NU, j = e - t * NU;
+            real z = zs[t * N + NX + j], d = at_z ? real(0) : ds[t * N + NX + j];
+            int ru = neq + t * 2 * NU + j;
+            real lu = lams[ru], ll = lams[ru + NU];
+            real bu = uhi(t, j), bl = ulo(t, j);
             real alpha = 1;
 #pragma unroll
             for (int k = 0; k < K; ++k) {
                 real zk = fma_(alpha, d, z);
-                real v = fma_(real(0.5) * Qv, zk, qv) * zk;
-                if (isu) {
-                    real vu = zk - bu, vl = -zk + bl;
-                    real cu = vu > 0 ? vu : real(0), cl = vl > 0 ? vl : real(0);
-                    v += fma_(lu, vu, ll * vl) + real(0.5) * rho * fma_(cu, cu, cl * cl);
-                }
-                acc[k] += v;
+                real vu = zk - bu, vl = bl - zk;
+                real cu = fmax_(vu, real(0)), cl = fmax_(vl, real(0));
+                acc[k] += fma_(lu, vu, ll * vl) + real(0.5) * rho * fma_(cu, cu, cl * cl);
                 alpha *= real(0.5);
             }
         }
-        for (int e = li; e < neq; e += G) {
-            real r = req[e], s = at_z ? real(0) : seq[e], lm = lams[e];
-            real alpha = 1;
+        c0 = team_sum<G>(c0);
+        c1 = team_sum<G>(c1);
+        c2 = team_sum<G>(c2);
+        real alpha = 1;
 #pragma unroll
-            for (int k = 0; k < K; ++k) {
-                real rk = fma_(alpha, s, r);
-                acc[k] += fma_(real(0.5) * rho * rk, rk, lm * rk);
-                alpha *= real(0.5);
-            }
+        for (int k = 0; k < K; ++k) {
+            phi[k] = team_sum<G>(acc[k]) + fma_(alpha, fma_(alpha, c2, c1), c0);
+            alpha *= real(0.5);
         }
-#pragma unroll
-        for (int k = 0; k < K; ++k) phi[k] = team_sum<G>(acc[k]);
     }
 
     // sum r+(z)^2 at the current zs/req (al_utils.py:552 sums this over the batch)
