@@ -44,6 +44,7 @@ def main():
     ap.add_argument("--nu", type=int, default=4)
     ap.add_argument("--al-iter", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--variant", default="auto", choices=["auto", "team", "quad"])
     args = ap.parse_args()
 
     import torch
@@ -84,7 +85,7 @@ def main():
     def step(i):
         be.solve_lin(dims, p.Qd, p.q, p.F, p.c, p.x0, p.u_lo, p.u_hi, 0, 0, zs[i], lams[i], rhos[i],
                      phi, rn2, info, status, al_iter=args.al_iter, max_newton=4, n_ls=20, flags=flags,
-                     rho_scale=10.0)
+                     rho_scale=10.0, variant=args.variant)
 
     def barrier():
         if world > 1:

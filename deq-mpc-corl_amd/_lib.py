@@ -13,7 +13,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libmi_alqp.so")
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 
 class AlqpDims(C.Structure):
@@ -22,7 +22,7 @@ class AlqpDims(C.Structure):
 
 class AlqpParams(C.Structure):
     _fields_ = [("al_iter", C.c_int), ("max_newton", C.c_int), ("n_ls", C.c_int),
-                ("flags", C.c_int), ("rho_scale", C.c_double)]
+                ("flags", C.c_int), ("rho_scale", C.c_double), ("variant", C.c_int)]
 
 
 class AlqpTrace(C.Structure):
@@ -33,6 +33,7 @@ class AlqpTrace(C.Structure):
 ALQP_INIT_MERIT = 1
 ALQP_DUAL_UPDATE = 2
 ALQP_SAVE_FACTOR = 4
+VARIANT_AUTO, VARIANT_TEAM, VARIANT_QUAD = 0, 1, 2
 
 ERRORS = {-1: "bad argument", -2: "unsupported (nx, nu) or horizon does not fit in LDS",
           -3: "kernel launch failed"}
@@ -42,7 +43,7 @@ _SIGS = {
     # name: (restype, argtypes) ; the f32/f64 pairs share a signature
     "alqp_solve_lin": (C.c_int, [C.POINTER(AlqpDims), C.POINTER(AlqpParams), _P, _P, _P, _P, _P, _P, _P,
                                  C.c_long, C.c_long, _P, _P, _P, _P, _P, _P, _P, _P,
-                                 C.POINTER(AlqpTrace), _P]),
+                                 C.POINTER(AlqpTrace), _P, C.c_size_t, _P]),
     "alqp_newton_step": (C.c_int, [C.POINTER(AlqpDims), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P,
                                    C.c_long, C.c_long, _P, _P, _P, _P, _P]),
     "alqp_merit": (C.c_int, [C.POINTER(AlqpDims), C.c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P,
@@ -57,6 +58,7 @@ _PLAIN = {
     "alqp_supported": (C.c_int, [C.POINTER(AlqpDims), C.c_int]),
     "alqp_lds_bytes": (C.c_size_t, [C.POINTER(AlqpDims), C.c_int]),
     "alqp_qps_per_wave": (C.c_int, [C.POINTER(AlqpDims), C.c_int]),
+    "alqp_workspace_bytes": (C.c_size_t, [C.POINTER(AlqpDims), C.c_int]),
 }
 
 EXPORTED_SYMBOLS = sorted([f"{n}_{s}" for n in _SIGS for s in ("f32", "f64")] + list(_PLAIN))

@@ -45,9 +45,26 @@ class HipBackend:
     """The product backend: thin argument marshalling over the C ABI."""
 
     name = "hip"
+    default_variant = "auto"
 
     def __init__(self):
         self.lib = _lib.load()
+        self._ws = {}  # (device, dtype) -> scratch tensor for the quad variant (grown on demand)
+
+    def workspace_bytes(self, B, T, nx, nu, dtype):
+        d = _lib.AlqpDims(B, T, nx, nu)
+        return int(self.lib.alqp_workspace_bytes(C.byref(d), int(dtype == torch.float64)))
+
+    def _workspace(self, dims, like):
+        """Device scratch for the quad variant, cached per (device, dtype). Contents need
+        not survive between calls; stream order protects reuse on one stream."""
+        need = self.workspace_bytes(*dims, like.dtype)
+        key = (like.device, like.dtype)
+        ws = self._ws.get(key)
+        if ws is None or ws.numel() * ws.element_size() < need:
+            ws = torch.empty(need // like.element_size() + 16, dtype=like.dtype, device=like.device)
+            self._ws[key] = ws
+        return ws, need
 
     # -- queries ---------------------------------------------------------------
     def supported(self, B, T, nx, nu, dtype):
@@ -66,12 +83,21 @@ class HipBackend:
     def solve_lin(self, dims, Qd, q, F, c, x0, ulo, uhi, sb_u, st_u, z, lam, rho, phi,
                   rnorm2=None, info=None, status=None, factor=None, al_iter=2, max_newton=4,
                   n_ls=20, flags=_lib.ALQP_INIT_MERIT | _lib.ALQP_DUAL_UPDATE, rho_scale=10.0,
-                  trace=None):
+                  trace=None, variant=None):
+        """variant: None/"auto" (quad unless a factor must be saved), "team", "quad"."""
         B, T, nx, nu = dims
         dt = z.dtype
         sfx = _dt(z)
         d = _lib.AlqpDims(B, T, nx, nu)
-        p = _lib.AlqpParams(al_iter, max_newton, n_ls, flags, rho_scale)
+        if variant is None:
+            variant = self.default_variant
+        vnum = {"auto": 0, "team": 1, "quad": 2}[variant]
+        if vnum == 0:
+            vnum = 1 if (flags & _lib.ALQP_SAVE_FACTOR) else 2
+        ws, ws_bytes = (None, 0)
+        if vnum == 2:
+            ws, ws_bytes = self._workspace(dims, z)
+        p = _lib.AlqpParams(al_iter, max_newton, n_ls, flags, rho_scale, vnum)
         tr = None
         if trace is not None:
             tr = _lib.AlqpTrace(*[
@@ -83,7 +109,8 @@ class HipBackend:
                 sb_u, st_u, _ptr(z, "z", dt), _ptr(lam, "lam", dt), _ptr(rho, "rho", dt),
                 _ptr(phi, "phi", dt), _ptr(rnorm2, "rnorm2", dt, True),
                 _ptr(info, "info", torch.int32, True), _ptr(status, "status", torch.uint8, True),
-                _ptr(factor, "factor", dt, True), C.byref(tr) if tr is not None else None, _stream())
+                _ptr(factor, "factor", dt, True), C.byref(tr) if tr is not None else None,
+                _ptr(ws, "workspace", dt, True), ws_bytes, _stream())
         _lib.check(rc, "alqp_solve_lin_" + sfx)
 
     def newton_step(self, dims, z, xnext, F, x0, lam, rho, Qd, q, ulo, uhi, sb_u, st_u, d_out,

@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 
 #include "alqp_team.hpp"
+#include "alqp_quad.hpp"
 #include "mi_alqp.h"
 
 namespace alqp {
@@ -188,6 +189,99 @@ __global__ __launch_bounds__(64, 2) void k_solve_lin(SolveArgs<real> a, TraceArg
             if (a.info) a.info[b] = tm.info;
             if (a.status) a.status[b] = bad ? 0 : 1;
         }
+    }
+}
+
+// ---- fused LinDx solve, quad variant (4 lanes per instance, HBM workspace) --------------
+template <typename real, int NX, int NU, bool TRACE>
+__global__ __launch_bounds__(64, 1) void k_solve_lin_quad(SolveArgs<real> a, TraceArgs<real> tr, real *ws) {
+    using C = QCfg<real, NX, NU>;
+    constexpr int N = C::N;
+    const int lane = threadIdx.x, qi = lane >> 2;
+    const int b_raw = blockIdx.x * 16 + qi;
+    const bool active = b_raw < a.B;
+    const int b = active ? b_raw : a.B - 1;
+    const int T = a.T, M = C::M(T);
+
+    Quad<real, NX, NU> qd;
+    qd.q = lane & 3;
+    qd.T = T;
+    qd.active = active;
+    qd.gQd = a.Qd + (size_t)b * T * N;
+    qd.gq = a.q + (size_t)b * T * N;
+    qd.gF = a.F + (size_t)b * (T - 1) * NX * N;
+    qd.gc = a.c + (size_t)b * (T - 1) * NX;
+    qd.gx0 = a.x0 + (size_t)b * NX;
+    qd.gulo = a.ulo + (size_t)b * a.sb_u;
+    qd.guhi = a.uhi + (size_t)b * a.sb_u;
+    qd.st_u = a.st_u;
+    qd.gz = a.z + (size_t)b * T * N;
+    qd.glam = a.lam + (size_t)b * M;
+    qd.rec = ws + (size_t)b * T * C::RECW;
+    qd.rho = a.rho[b];
+    qd.info = 0;
+    real phi_prev = a.phi[b];
+    qd.residual_pass();
+
+    int step_id = 0;
+    for (int it = 0; it < a.al_iter; ++it) {
+        if (a.flags & ALQP_INIT_MERIT) {
+            real p1[1];
+            qd.template merit_candidates<1>(p1, true);
+            phi_prev = p1[0];
+        }
+        for (int st = 0; st < a.max_newton; ++st, ++step_id) {
+            real *tg = nullptr;
+            if constexpr (TRACE) tg = (tr.g && active) ? tr.g + ((size_t)step_id * a.B + b) * T * N : nullptr;
+            qd.forward(tg);
+            qd.backward();
+            if constexpr (TRACE) {
+                if (tr.d && active) {
+                    real *td = tr.d + ((size_t)step_id * a.B + b) * T * N;
+                    for (int t = 0; t < T; ++t)
+                        for (int j = qd.q; j < N; j += 4) td[t * N + j] = qd.recp(t)[C::oY + j];
+                }
+            }
+            real ph[20];
+            qd.template merit_candidates<20>(ph, false);
+            int kbest = 0;
+            real best = ph[0];
+#pragma unroll
+            for (int k = 1; k < 20; ++k) {
+                if (k < a.n_ls && !(best != best) && (ph[k] != ph[k] || ph[k] < best)) {
+                    best = ph[k];
+                    kbest = k;
+                }
+            }
+            const bool acc = best < phi_prev;
+            if constexpr (TRACE) {
+                if (active && qd.q == 0) {
+                    if (tr.phi)
+#pragma unroll
+                        for (int k = 0; k < 20; ++k)
+                            if (k < a.n_ls) tr.phi[((size_t)step_id * a.n_ls + k) * a.B + b] = ph[k];
+                    if (tr.phi_prev) tr.phi_prev[(size_t)step_id * a.B + b] = phi_prev;
+                    if (tr.k) tr.k[(size_t)step_id * a.B + b] = kbest;
+                    if (tr.accept) tr.accept[(size_t)step_id * a.B + b] = acc ? 1 : 0;
+                }
+            }
+            const real alpha = acc ? real(1) / real(1 << kbest) : real(0);
+            qd.apply_step(alpha);
+            phi_prev = best;  // merit <- new_merit even when rejected (al_utils.py:569)
+        }
+        if (a.flags & ALQP_DUAL_UPDATE) {
+            qd.dual_update();
+            qd.rho *= a.rho_scale;
+        }
+    }
+    int bad = 0;
+    const real rn2 = qd.rplus2(bad);
+    if (active && qd.q == 0) {
+        a.rho[b] = qd.rho;
+        a.phi[b] = phi_prev;
+        if (a.rnorm2) a.rnorm2[b] = rn2;
+        if (a.info) a.info[b] = qd.info;
+        if (a.status) a.status[b] = bad ? 0 : 1;
     }
 }
 
@@ -429,6 +523,35 @@ int dispatch_solve(int nx, int nu, const SolveArgs<real> &a, const TraceArgs<rea
     return ALQP_E_UNSUPPORTED;
 }
 
+template <typename real, int NX, int NU, typename Fn, typename... Args>
+int launch_quad_kernel(Fn fn, int B, hipStream_t stream, Args... args) {
+    const unsigned grid = (unsigned)((B + 15) / 16);
+    hipLaunchKernelGGL(fn, dim3(grid), dim3(64), 0, stream, args...);
+    return hipGetLastError() == hipSuccess ? 0 : ALQP_E_LAUNCH;
+}
+
+template <typename real>
+int dispatch_solve_quad(int nx, int nu, const SolveArgs<real> &a, const TraceArgs<real> *tr, real *ws,
+                        hipStream_t stream) {
+#define X(NX, NU)                                                                                       \
+    if (nx == NX && nu == NU) {                                                                         \
+        if (tr) return launch_quad_kernel<real, NX, NU>(k_solve_lin_quad<real, NX, NU, true>, a.B, stream, a, *tr, ws); \
+        return launch_quad_kernel<real, NX, NU>(k_solve_lin_quad<real, NX, NU, false>, a.B, stream, a, TraceArgs<real>{}, ws); \
+    }
+    ALQP_FOR_EACH_DIMS(X)
+#undef X
+    return ALQP_E_UNSUPPORTED;
+}
+
+template <typename real>
+size_t quad_ws_bytes(int nx, int nu, int B, int T) {
+#define X(NX, NU) \
+    if (nx == NX && nu == NU) return QCfg<real, NX, NU>::ws_words(B, T) * sizeof(real);
+    ALQP_FOR_EACH_DIMS(X)
+#undef X
+    return 0;
+}
+
 template <typename real>
 int dispatch_step(int nx, int nu, const StepArgs<real> &a, hipStream_t stream) {
 #define X(NX, NU) \
@@ -471,7 +594,7 @@ int solve_lin_impl(const AlqpDims *dims, const AlqpParams *prm, const void *Qd, 
                    const void *F, const void *c, const void *x0, const void *u_lo, const void *u_hi,
                    long sb_u, long st_u, void *z, void *lam, void *rho, void *phi, void *rnorm2,
                    int *info, unsigned char *status, void *factor_out, const AlqpTrace *trace,
-                   void *stream) {
+                   void *workspace, size_t ws_bytes, void *stream) {
     if (!dims_ok(dims) || !prm || !Qd || !q || !F || !c || !x0 || !u_lo || !u_hi || !z || !lam || !rho || !phi)
         return ALQP_E_BADARG;
     if (prm->n_ls < 1 || prm->n_ls > 20 || prm->al_iter < 0 || prm->max_newton < 0) return ALQP_E_BADARG;
@@ -490,6 +613,19 @@ int solve_lin_impl(const AlqpDims *dims, const AlqpParams *prm, const void *Qd, 
         tr.g = (real *)trace->g; tr.d = (real *)trace->d; tr.phi = (real *)trace->phi;
         tr.phi_prev = (real *)trace->phi_prev; tr.k = trace->k; tr.accept = trace->accept;
     }
+    // variant: 1 = team (factor in LDS), 2 = quad (4 lanes/instance, HBM workspace), 0 = auto
+    const size_t need = quad_ws_bytes<real>(dims->nx, dims->nu, dims->B, dims->T);
+    int variant = prm->variant;
+    if (variant == 0)
+        variant = (need > 0 && workspace && ws_bytes >= need && !(prm->flags & ALQP_SAVE_FACTOR)) ? 2 : 1;
+    if (variant == 2) {
+        if (prm->flags & ALQP_SAVE_FACTOR) return ALQP_E_UNSUPPORTED;
+        if (need == 0) return ALQP_E_UNSUPPORTED;
+        if (!workspace || ws_bytes < need) return ALQP_E_BADARG;
+        return dispatch_solve_quad<real>(dims->nx, dims->nu, a, trace ? &tr : nullptr, (real *)workspace,
+                                         (hipStream_t)stream);
+    }
+    if (variant != 1) return ALQP_E_BADARG;
     return dispatch_solve<real>(dims->nx, dims->nu, a, trace ? &tr : nullptr, (hipStream_t)stream);
 }
 
@@ -570,7 +706,13 @@ int dual_impl(const AlqpDims *dims, const void *z, const void *xnext, const void
 // ---- C ABI -------------------------------------------------------------------------------
 extern "C" {
 
-int alqp_abi_version(void) { return 1; }
+int alqp_abi_version(void) { return 2; }
+
+size_t alqp_workspace_bytes(const AlqpDims *dims, int is_f64) {
+    if (!alqp::dims_ok(dims)) return 0;
+    return is_f64 ? alqp::quad_ws_bytes<double>(dims->nx, dims->nu, dims->B, dims->T)
+                  : alqp::quad_ws_bytes<float>(dims->nx, dims->nu, dims->B, dims->T);
+}
 
 size_t alqp_lds_bytes(const AlqpDims *dims, int is_f64) {
     if (!alqp::dims_ok(dims)) return 0;
@@ -596,9 +738,10 @@ int alqp_qps_per_wave(const AlqpDims *dims, int is_f64) {
                              const void *u_lo, const void *u_hi, long sb_u, long st_u, void *z,       \
                              void *lam, void *rho, void *phi, void *rnorm2, int *info,                \
                              unsigned char *status, void *factor_out, const AlqpTrace *trace,         \
-                             void *stream) {                                                          \
+                             void *workspace, size_t ws_bytes, void *stream) {                        \
         return alqp::solve_lin_impl<REAL>(dims, prm, Qd, q, F, c, x0, u_lo, u_hi, sb_u, st_u, z, lam, \
-                                          rho, phi, rnorm2, info, status, factor_out, trace, stream); \
+                                          rho, phi, rnorm2, info, status, factor_out, trace,          \
+                                          workspace, ws_bytes, stream);                               \
     }                                                                                                 \
     int alqp_newton_step_##SFX(const AlqpDims *dims, const void *z, const void *xnext, const void *F, \
                                const void *x0, const void *lam, const void *rho, const void *Qd,      \

@@ -1,0 +1,576 @@
+// alqp_quad.hpp - "quad" variant of the fused LinDx solve: FOUR lanes per QP instance,
+// 16 instances per 64-lane wavefront (gfx950 / MI355X only).
+//
+// Why a second variant. In the team variant (alqp_team.hpp) the whole factor lives in
+// LDS: traffic stays at the algorithmic minimum, but 20 KB of LDS per instance caps a
+// CU at 8 instances and a 64-lane wave works on a 17-wide problem (lane utilisation
+// ~10 %). Here the n x n blocks are small enough that FOUR lanes hold a stage's panel
+// entirely in registers (rows dealt cyclically, row i on lane i % 4) and every
+// cross-lane operand is a DPP quad broadcast (a VALU operand modifier, no LDS, no
+// v_readlane): ~6x fewer wave instructions per solve. The price: the per-stage factor
+// (lower triangle of L_tt, ~1 KB) and the vectors y/d, r, s are streamed through an
+// HBM workspace, written in the forward sweep and read back in the backward sweep /
+// line search. MI355X's 8 TB/s HBM is otherwise idle on this problem (the team variant
+// moves 0.05 TB/s), so spending bandwidth to buy lane utilisation is the right trade.
+//
+// Workspace discipline: every word of the workspace is only ever read by the lane that
+// wrote it (same-thread RAW through global memory needs no fence).
+//
+// Forward stage t (right-looking panel factorisation, all loops fully unrolled):
+//   rows of H_tt (slot s, lane q: row 4s+q), rows of -rho F_t, the replicated rhs row;
+//   pivot j: broadcast pivot, v_rsq, scale column j, rank-1 update of the trailing
+//   columns (one DPP broadcast of L[k][j] per (j,k) pair), and the Schur complement
+//   W_t W_t' / W_t y_t for stage t+1 accumulated in the same pass.
+// Backward stage t: d_t = L^{-T} ( y_t + rho L^{-1} F_t' dx_{t+1} ) by substitution on
+//   replicated vectors, s_t = dx_{t+1} - F_t d_t.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "alqp_team.hpp"  // fma_, rsqrt_, fmax_, fabs_, pad4
+
+namespace alqp {
+
+// ---- quad-level cross-lane primitives (DPP quad_perm) ------------------------------
+template <int Q>
+__device__ inline float qb(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), Q * 0x55, 0xF, 0xF, true));
+}
+template <int Q>
+__device__ inline double qb(double v) {
+    long long b = __builtin_bit_cast(long long, v);
+    int lo = __builtin_amdgcn_mov_dpp((int)(b & 0xffffffffll), Q * 0x55, 0xF, 0xF, true);
+    int hi = __builtin_amdgcn_mov_dpp((int)(b >> 32), Q * 0x55, 0xF, 0xF, true);
+    return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
+}
+// broadcast from quad lane `src`; src is a compile-time constant after unrolling, the switch
+// folds away (the builtin needs a literal control word at each call site)
+template <typename real>
+__device__ inline real qbv(real v, int src) {
+    switch (src & 3) {
+        case 0: return qb<0>(v);
+        case 1: return qb<1>(v);
+        case 2: return qb<2>(v);
+        default: return qb<3>(v);
+    }
+}
+template <int CTRL>
+__device__ inline float qperm(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+template <int CTRL>
+__device__ inline double qperm(double v) {
+    long long b = __builtin_bit_cast(long long, v);
+    int lo = __builtin_amdgcn_mov_dpp((int)(b & 0xffffffffll), CTRL, 0xF, 0xF, true);
+    int hi = __builtin_amdgcn_mov_dpp((int)(b >> 32), CTRL, 0xF, 0xF, true);
+    return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
+}
+// all-reduce over the 4 lanes of a quad
+template <typename real>
+__device__ inline real qsum(real v) {
+    v += qperm<0xB1>(v);  // quad_perm [1,0,3,2]
+    v += qperm<0x4E>(v);  // quad_perm [2,3,0,1]
+    return v;
+}
+__device__ inline int qor(int v) {
+    v |= __builtin_amdgcn_mov_dpp(v, 0xB1, 0xF, 0xF, true);
+    v |= __builtin_amdgcn_mov_dpp(v, 0x4E, 0xF, 0xF, true);
+    return v;
+}
+// element q of (a0,a1,a2,a3), q = lane within the quad
+template <typename real>
+__device__ inline real sel4(real a0, real a1, real a2, real a3, int q) {
+    real lo = (q & 1) ? a1 : a0, hi = (q & 1) ? a3 : a2;
+    return (q & 2) ? hi : lo;
+}
+
+// ---- 4-byte-aligned vector access to global memory ----------------------------------
+struct __attribute__((packed, aligned(4))) f4u { float x, y, z, w; };
+struct __attribute__((packed, aligned(8))) d4u { double x, y, z, w; };
+__device__ inline void gld4(const float *p, float &a, float &b, float &c, float &d) {
+    f4u t = *reinterpret_cast<const f4u *>(p);
+    a = t.x; b = t.y; c = t.z; d = t.w;
+}
+__device__ inline void gld4(const double *p, double &a, double &b, double &c, double &d) {
+    d4u t = *reinterpret_cast<const d4u *>(p);
+    a = t.x; b = t.y; c = t.z; d = t.w;
+}
+__device__ inline void gst4(float *p, float a, float b, float c, float d) {
+    f4u t; t.x = a; t.y = b; t.z = c; t.w = d;
+    *reinterpret_cast<f4u *>(p) = t;
+}
+__device__ inline void gst4(double *p, double a, double b, double c, double d) {
+    d4u t; t.x = a; t.y = b; t.z = c; t.w = d;
+    *reinterpret_cast<d4u *>(p) = t;
+}
+// LEN contiguous reals into a register array (static indices only)
+template <int LEN, typename real>
+__device__ inline void gload(const real *p, real (&dst)[LEN]) {
+#pragma unroll
+    for (int c = 0; c + 4 <= LEN; c += 4) gld4(p + c, dst[c], dst[c + 1], dst[c + 2], dst[c + 3]);
+#pragma unroll
+    for (int c = (LEN / 4) * 4; c < LEN; ++c) dst[c] = p[c];
+}
+
+template <typename real, int NX_, int NU_>
+struct QCfg {
+    static constexpr int NX = NX_, NU = NU_, N = NX_ + NU_;
+    static constexpr int SH = (N + 3) / 4;   // slots of H rows per lane (row 4s+q)
+    static constexpr int SW = (NX + 3) / 4;  // slots of W / F rows per lane
+    static constexpr int SY = SH;            // own elements of an n-vector (k = 4m+q)
+    static constexpr int HT = 2 * SH * (SH + 1);  // registers of the trimmed H panel: slot s has 4(s+1) columns
+    __host__ __device__ static constexpr int hidx(int s, int j) { return 2 * s * (s + 1) + j; }
+    static constexpr int ST = 2 * SW * (SW + 1);  // same trimming for the Schur accumulator
+    // workspace record of one (instance, stage), in reals
+    static constexpr int LCH = SH * (SH + 1) / 2;  // 4-word chunks of L per lane
+    static constexpr int oL = 0;
+    static constexpr int oY = oL + LCH * 16;       // y_t, later d_t : element k at oY + k
+    static constexpr int oR = oY + 4 * SY;         // r_t (eq residual of row block t): row r at oR + r
+    static constexpr int oS = oR + 4 * SW;         // s_t = (J d)_eq
+    static constexpr int RECW = oS + 4 * SW;
+    __host__ __device__ static constexpr int M(int T) { return T * NX + 2 * T * NU; }
+    __host__ __device__ static constexpr size_t ws_words(int B, int T) { return (size_t)B * T * RECW; }
+};
+
+template <typename real, int NX, int NU>
+struct Quad {
+    using C = QCfg<real, NX, NU>;
+    static constexpr int N = C::N, SH = C::SH, SW = C::SW, SY = C::SY, HT = C::HT, ST = C::ST, RECW = C::RECW;
+
+    int q, T;
+    bool active;
+    const real *gQd, *gq, *gF, *gc, *gx0, *gulo, *guhi;
+    long st_u;
+    real *gz, *glam, *rec;
+    real rho;
+    int info;
+
+    __device__ real uhi(int t, int j) const { return guhi[t * st_u + j]; }
+    __device__ real ulo(int t, int j) const { return gulo[t * st_u + j]; }
+    __device__ real *recp(int t) const { return rec + (size_t)t * RECW; }
+
+    // F_t rows of this lane: row 4s+q (zeros for rows >= NX)
+    __device__ void load_F_rows(int t, real (&W)[SW][N]) const {
+        const real *Fg = gF + (size_t)t * NX * N;
+#pragma unroll
+        for (int s = 0; s < SW; ++s) {
+            const int r = 4 * s + q;
+            if (4 * s + 3 < NX || r < NX) {
+                gload<N>(Fg + r * N, W[s]);
+            } else {
+#pragma unroll
+                for (int k = 0; k < N; ++k) W[s][k] = 0;
+            }
+        }
+    }
+
+    // equality residuals of all stages at the current z -> workspace (kernel start)
+    __device__ void residual_pass() {
+        for (int t = 0; t < T - 1; ++t) {
+            real W[SW][N], zt[N];
+            load_F_rows(t, W);
+            gload<N>(gz + t * N, zt);
+#pragma unroll
+            for (int s = 0; s < SW; ++s) {
+                const int r = 4 * s + q;
+                if (r < NX) {
+                    real xn = gc[t * NX + r];
+#pragma unroll
+                    for (int k = 0; k < N; ++k) xn = fma_(W[s][k], zt[k], xn);
+                    if (active) recp(t)[C::oR + r] = gz[(t + 1) * N + r] - xn;
+                }
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < SW; ++s) {
+            const int r = 4 * s + q;
+            if (r < NX && active) recp(T - 1)[C::oR + r] = gz[r] - gx0[r];
+        }
+    }
+
+    // ---- forward sweep: gradient, factorisation, forward substitution ------------------
+    __device__ void forward(real *g_out) {
+        real S[ST], Sy[SW];
+        real vprev[NX], Syrep[NX];
+#pragma unroll
+        for (int i = 0; i < ST; ++i) S[i] = 0;
+#pragma unroll
+        for (int s = 0; s < SW; ++s) Sy[s] = 0;
+        // stage 0: x_0 is pinned by the initial-state rows (eq row block T-1), al_utils.py:274
+        {
+            real z0[NX], xi[NX], li[NX];
+            gload<NX>(gz, z0);
+            gload<NX>(gx0, xi);
+            gload<NX>(glam + (T - 1) * NX, li);
+#pragma unroll
+            for (int j = 0; j < NX; ++j) {
+                real r = z0[j] - xi[j];
+                vprev[j] = fma_(rho, r, li[j]);
+                Syrep[j] = 0;
+                if ((j & 3) == q && active) recp(T - 1)[C::oR + j] = r;
+            }
+        }
+        for (int t = 0; t < T; ++t) {
+            const bool dyn = t < T - 1;
+            real W[SW][N];
+            real Y[N], D[N];
+            real v[SW];
+            real *rp = recp(t);
+            // ---- loads + residual + multiplier estimate
+            {
+                real zt[N], Qt[N], qt[N];
+                gload<N>(gz + t * N, zt);
+                gload<N>(gQd + t * N, Qt);
+                gload<N>(gq + t * N, qt);
+                if (dyn) load_F_rows(t, W);
+                else {
+#pragma unroll
+                    for (int s = 0; s < SW; ++s)
+#pragma unroll
+                        for (int k = 0; k < N; ++k) W[s][k] = 0;
+                }
+#pragma unroll
+                for (int s = 0; s < SW; ++s) {
+                    const int r = 4 * s + q;
+                    v[s] = 0;
+                    if (dyn && r < NX) {
+                        real xn = gc[t * NX + r];
+#pragma unroll
+                        for (int k = 0; k < N; ++k) xn = fma_(W[s][k], zt[k], xn);
+                        real rr = gz[(t + 1) * N + r] - xn;
+                        v[s] = fma_(rho, rr, glam[t * NX + r]);
+                        if (active) rp[C::oR + r] = rr;
+                    }
+                }
+                // ---- gradient (replicated in the 4 lanes) and diagonal of H_tt
+#pragma unroll
+                for (int j = 0; j < N; ++j) {
+                    real g = fma_(Qt[j], zt[j], qt[j]);
+                    real d = Qt[j];
+                    if (j < NX) {
+                        g += vprev[j];
+                        d += rho;
+                    } else {
+                        const int ju = j - NX;
+                        real vu = zt[j] - uhi(t, ju), vl = -zt[j] + ulo(t, ju);
+                        real lu = glam[T * NX + t * 2 * NU + ju], ll = glam[T * NX + t * 2 * NU + NU + ju];
+                        real au = vu >= 0 ? real(1) : real(0), al = vl >= 0 ? real(1) : real(0);
+                        d = fma_(rho, au + al, d);
+                        g += fma_(rho, fmax_(vu, real(0)), lu) - fma_(rho, fmax_(vl, real(0)), ll);
+                    }
+                    if (dyn) {
+                        real p = 0;
+#pragma unroll
+                        for (int s = 0; s < SW; ++s) p = fma_(W[s][j], v[s], p);
+                        g -= qsum(p);
+                    }
+                    D[j] = d;
+                    Y[j] = -g - ((j < NX) ? Syrep[j] : real(0));
+                    if (g_out && (j & 3) == q) g_out[t * N + j] = g;
+                }
+            }
+            // ---- H_tt rows (lower part, trimmed): diag + (1/rho) w_i w_j - Schur
+            real H[HT];
+#pragma unroll
+            for (int i = 0; i < HT; ++i) H[i] = 0;
+#pragma unroll
+            for (int s = 0; s < SH; ++s)
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+                    if (4 * s + c < N) H[C::hidx(s, 4 * s + c)] = (q == c) ? D[4 * s + c] : real(0);
+            // W <- -rho F_t  (the F'F term is then (1/rho) W'W)
+#pragma unroll
+            for (int s = 0; s < SW; ++s)
+#pragma unroll
+                for (int k = 0; k < N; ++k) W[s][k] *= -rho;
+            if (dyn) {
+                const real irho = real(1) / rho;
+#pragma unroll
+                for (int r = 0; r < NX; ++r) {
+                    real fr[N];
+#pragma unroll
+                    for (int j = 0; j < N; ++j) fr[j] = qbv(W[r >> 2][j], r);
+#pragma unroll
+                    for (int s = 0; s < SH; ++s) {
+                        real fi = sel4(fr[4 * s], (4 * s + 1 < N) ? fr[(4 * s + 1 < N) ? 4 * s + 1 : 0] : real(0),
+                                       (4 * s + 2 < N) ? fr[(4 * s + 2 < N) ? 4 * s + 2 : 0] : real(0),
+                                       (4 * s + 3 < N) ? fr[(4 * s + 3 < N) ? 4 * s + 3 : 0] : real(0), q) * irho;
+#pragma unroll
+                        for (int j = 0; j < 4 * s + 4; ++j)
+                            if (j < N) H[C::hidx(s, j)] = fma_(fi, fr[j], H[C::hidx(s, j)]);
+                    }
+                }
+            }
+            if (t > 0) {
+#pragma unroll
+                for (int s = 0; s < SW; ++s)
+#pragma unroll
+                    for (int b = 0; b < 4 * s + 4; ++b)
+                        if (b < NX) H[C::hidx(s, b)] -= S[C::hidx(s, b)];
+            }
+#pragma unroll
+            for (int i = 0; i < ST; ++i) S[i] = 0;
+#pragma unroll
+            for (int s = 0; s < SW; ++s) Sy[s] = 0;
+            // ---- right-looking panel factorisation
+#pragma unroll
+            for (int j = 0; j < N; ++j) {
+                const real p = qbv(H[C::hidx(j >> 2, j)], j);
+                if (!(p > 0) && info == 0) info = t * N + j + 1;
+                const real rinv = rsqrt_(p);
+#pragma unroll
+                for (int s = (j >> 2); s < SH; ++s) H[C::hidx(s, j)] *= rinv;
+#pragma unroll
+                for (int s = 0; s < SW; ++s) W[s][j] *= rinv;
+                Y[j] *= rinv;
+#pragma unroll
+                for (int k = j + 1; k < N; ++k) {
+                    const real lkj = qbv(H[C::hidx(k >> 2, j)], k);
+#pragma unroll
+                    for (int s = (k >> 2); s < SH; ++s) H[C::hidx(s, k)] = fma_(-H[C::hidx(s, j)], lkj, H[C::hidx(s, k)]);
+#pragma unroll
+                    for (int s = 0; s < SW; ++s) W[s][k] = fma_(-W[s][j], lkj, W[s][k]);
+                    Y[k] = fma_(-Y[j], lkj, Y[k]);
+                }
+                // the solves divide by L[j][j]: keep 1/L[j][j] on the diagonal
+                H[C::hidx(j >> 2, j)] = (q == (j & 3)) ? rinv : H[C::hidx(j >> 2, j)];
+                if (dyn) {
+#pragma unroll
+                    for (int b = 0; b < NX; ++b) {
+                        const real wbj = qbv(W[b >> 2][j], b);
+#pragma unroll
+                        for (int s = (b >> 2); s < SW; ++s) S[C::hidx(s, b)] = fma_(W[s][j], wbj, S[C::hidx(s, b)]);
+                    }
+#pragma unroll
+                    for (int s = 0; s < SW; ++s) Sy[s] = fma_(W[s][j], Y[j], Sy[s]);
+                }
+            }
+            // ---- stage results -> workspace (each lane its own words)
+            if (active) {
+#pragma unroll
+                for (int s = 0; s < SH; ++s)
+#pragma unroll
+                    for (int c = 0; c <= s; ++c)
+                        gst4(rp + C::oL + ((s * (s + 1)) / 2 + c) * 16 + 4 * q, H[C::hidx(s, 4 * c)],
+                             H[C::hidx(s, 4 * c + 1)], H[C::hidx(s, 4 * c + 2)], H[C::hidx(s, 4 * c + 3)]);
+#pragma unroll
+                for (int j = 0; j < N; ++j)
+                    if ((j & 3) == q) rp[C::oY + j] = Y[j];
+            }
+            // ---- carry to the next stage: replicated v = lam + rho r and W_t y_t
+#pragma unroll
+            for (int j = 0; j < NX; ++j) {
+                vprev[j] = qbv(v[j >> 2], j);
+                Syrep[j] = qbv(Sy[j >> 2], j);
+            }
+        }
+    }
+
+    // ---- backward sweep ---------------------------------------------------------------
+    __device__ void backward() {
+        real dxn[NX];
+#pragma unroll
+        for (int j = 0; j < NX; ++j) dxn[j] = 0;
+        for (int t = T - 1; t >= 0; --t) {
+            const bool dyn = t < T - 1;
+            real *rp = recp(t);
+            real H[HT];
+#pragma unroll
+            for (int s = 0; s < SH; ++s)
+#pragma unroll
+                for (int c = 0; c <= s; ++c)
+                    gld4(rp + C::oL + ((s * (s + 1)) / 2 + c) * 16 + 4 * q, H[C::hidx(s, 4 * c)],
+                         H[C::hidx(s, 4 * c + 1)], H[C::hidx(s, 4 * c + 2)], H[C::hidx(s, 4 * c + 3)]);
+            real yo[SY];
+#pragma unroll
+            for (int m = 0; m < SY; ++m) yo[m] = (4 * m + q < N) ? rp[C::oY + 4 * m + q] : real(0);
+            real Y[N];
+#pragma unroll
+            for (int j = 0; j < N; ++j) Y[j] = qbv(yo[j >> 2], j);
+            real W[SW][N];
+            real dxs[SW];
+#pragma unroll
+            for (int s = 0; s < SW; ++s)
+                dxs[s] = sel4(dxn[4 * s], (4 * s + 1 < NX) ? dxn[(4 * s + 1 < NX) ? 4 * s + 1 : 0] : real(0),
+                              (4 * s + 2 < NX) ? dxn[(4 * s + 2 < NX) ? 4 * s + 2 : 0] : real(0),
+                              (4 * s + 3 < NX) ? dxn[(4 * s + 3 < NX) ? 4 * s + 3 : 0] : real(0), q);
+            if (dyn) {
+                load_F_rows(t, W);
+                // v = F_t' dx_{t+1}
+                real vv[N];
+#pragma unroll
+                for (int j = 0; j < N; ++j) {
+                    real p = 0;
+#pragma unroll
+                    for (int s = 0; s < SW; ++s) p = fma_(W[s][j], dxs[s], p);
+                    vv[j] = qsum(p);
+                }
+                // w = L^{-1} v
+#pragma unroll
+                for (int j = 0; j < N; ++j) {
+                    const real wj = vv[j] * qbv(H[C::hidx(j >> 2, j)], j);
+                    vv[j] = wj;
+#pragma unroll
+                    for (int k = j + 1; k < N; ++k) vv[k] = fma_(-qbv(H[C::hidx(k >> 2, j)], k), wj, vv[k]);
+                }
+#pragma unroll
+                for (int j = 0; j < N; ++j) Y[j] = fma_(rho, vv[j], Y[j]);
+            }
+            // d = L^{-T} rhs
+#pragma unroll
+            for (int i = N - 1; i >= 0; --i) {
+                const real di = Y[i] * qbv(H[C::hidx(i >> 2, i)], i);
+                Y[i] = di;
+#pragma unroll
+                for (int j = 0; j < i; ++j) Y[j] = fma_(-qbv(H[C::hidx(i >> 2, j)], i), di, Y[j]);
+            }
+            if (active) {
+#pragma unroll
+                for (int j = 0; j < N; ++j)
+                    if ((j & 3) == q) rp[C::oY + j] = Y[j];
+            }
+            if (dyn) {
+#pragma unroll
+                for (int s = 0; s < SW; ++s) {
+                    const int r = 4 * s + q;
+                    real p = 0;
+#pragma unroll
+                    for (int k = 0; k < N; ++k) p = fma_(W[s][k], Y[k], p);
+                    if (r < NX && active) rp[C::oS + r] = dxs[s] - p;
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < NX; ++j) dxn[j] = Y[j];
+        }
+        // initial-state rows: s = d_0[x]
+#pragma unroll
+        for (int j = 0; j < NX; ++j)
+            if ((j & 3) == q && active) recp(T - 1)[C::oS + j] = dxn[j];
+    }
+
+    // ---- merit of K candidates (see Team::merit_candidates for the algebra) ---------------
+    template <int K>
+    __device__ void merit_candidates(real (&phi)[K], bool at_z) {
+        real c0 = 0, c1 = 0, c2 = 0;
+        real acc[K];
+#pragma unroll
+        for (int k = 0; k < K; ++k) acc[k] = 0;
+        for (int t = 0; t < T; ++t) {
+            const real *rp = recp(t);
+#pragma unroll
+            for (int m = 0; m < SY; ++m) {
+                const int j = 4 * m + q;
+                if (4 * m + 3 < N || j < N) {
+                    real z = gz[t * N + j], d = at_z ? real(0) : rp[C::oY + j];
+                    real Qv = gQd[t * N + j], qv = gq[t * N + j];
+                    c0 = fma_(fma_(real(0.5) * Qv, z, qv), z, c0);
+                    c1 = fma_(fma_(Qv, z, qv), d, c1);
+                    c2 = fma_(real(0.5) * Qv * d, d, c2);
+                    if (j >= NX) {
+                        const int ju = j - NX;
+                        real lu = glam[T * NX + t * 2 * NU + ju], ll = glam[T * NX + t * 2 * NU + NU + ju];
+                        real bu = uhi(t, ju), bl = ulo(t, ju);
+                        real alpha = 1;
+#pragma unroll
+                        for (int k = 0; k < K; ++k) {
+                            real zk = fma_(alpha, d, z);
+                            real vu = zk - bu, vl = bl - zk;
+                            real cu = fmax_(vu, real(0)), cl = fmax_(vl, real(0));
+                            acc[k] += fma_(lu, vu, ll * vl) + real(0.5) * rho * fma_(cu, cu, cl * cl);
+                            alpha *= real(0.5);
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int s = 0; s < SW; ++s) {
+                const int r = 4 * s + q;
+                if (4 * s + 3 < NX || r < NX) {
+                    real rr = rp[C::oR + r], sv = at_z ? real(0) : rp[C::oS + r], lm = glam[t * NX + r];
+                    c0 = fma_(fma_(real(0.5) * rho, rr, lm), rr, c0);
+                    c1 = fma_(fma_(rho, rr, lm), sv, c1);
+                    c2 = fma_(real(0.5) * rho * sv, sv, c2);
+                }
+            }
+        }
+        c0 = qsum(c0);
+        c1 = qsum(c1);
+        c2 = qsum(c2);
+        real alpha = 1;
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            phi[k] = qsum(acc[k]) + fma_(alpha, fma_(alpha, c2, c1), c0);
+            alpha *= real(0.5);
+        }
+    }
+
+    // z += alpha d ; r += alpha s   (own elements only)
+    __device__ void apply_step(real alpha) {
+        if (!active) return;
+        for (int t = 0; t < T; ++t) {
+            real *rp = recp(t);
+#pragma unroll
+            for (int m = 0; m < SY; ++m) {
+                const int j = 4 * m + q;
+                if (j < N) gz[t * N + j] = fma_(alpha, rp[C::oY + j], gz[t * N + j]);
+            }
+#pragma unroll
+            for (int s = 0; s < SW; ++s) {
+                const int r = 4 * s + q;
+                if (r < NX) rp[C::oR + r] = fma_(alpha, rp[C::oS + r], rp[C::oR + r]);
+            }
+        }
+    }
+
+    __device__ real rplus2(int &bad) {
+        real acc = 0;
+        for (int t = 0; t < T; ++t) {
+            const real *rp = recp(t);
+#pragma unroll
+            for (int s = 0; s < SW; ++s) {
+                const int r = 4 * s + q;
+                if (r < NX) { real rr = rp[C::oR + r]; acc = fma_(rr, rr, acc); }
+            }
+#pragma unroll
+            for (int m = 0; m < SY; ++m) {
+                const int j = 4 * m + q;
+                if (j < N) {
+                    real z = gz[t * N + j];
+                    bad |= !(z - z == real(0));
+                    if (j >= NX) {
+                        real cu = fmax_(z - uhi(t, j - NX), real(0)), cl = fmax_(ulo(t, j - NX) - z, real(0));
+                        acc += fma_(cu, cu, cl * cl);
+                    }
+                }
+            }
+        }
+        bad = qor(bad);
+        return qsum(acc);
+    }
+
+    // lam <- lam + rho r ; lam_ineq <- max(0, .)   (AL_mpc.py:316-317)
+    __device__ void dual_update() {
+        if (!active) return;
+        for (int t = 0; t < T; ++t) {
+            const real *rp = recp(t);
+#pragma unroll
+            for (int s = 0; s < SW; ++s) {
+                const int r = 4 * s + q;
+                if (r < NX) glam[t * NX + r] = fma_(rho, rp[C::oR + r], glam[t * NX + r]);
+            }
+#pragma unroll
+            for (int m = 0; m < SY; ++m) {
+                const int j = 4 * m + q;
+                if (j >= NX && j < N) {
+                    const int ju = j - NX;
+                    real u = gz[t * N + j];
+                    real *lu = glam + T * NX + t * 2 * NU + ju, *ll = lu + NU;
+                    real a = fma_(rho, u - uhi(t, ju), *lu), c = fma_(rho, ulo(t, ju) - u, *ll);
+                    *lu = a < 0 ? real(0) : a;
+                    *ll = c < 0 ? real(0) : c;
+                }
+            }
+        }
+    }
+};
+
+}  // namespace alqp

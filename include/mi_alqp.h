@@ -56,6 +56,9 @@ typedef struct AlqpParams {
     int n_ls;         /* line-search candidates 2^-k, reference: 20 (al_utils.py:619); <= 20 */
     int flags;        /* ALQP_* */
     double rho_scale; /* reference: 10 (AL_mpc.py:325) */
+    int variant;      /* kernel variant of alqp_solve_lin: 0 auto, 1 team (factor in LDS, no
+                         workspace), 2 quad (4 lanes per instance, factor streamed through the
+                         HBM workspace; no ALQP_SAVE_FACTOR) */
 } AlqpParams;
 
 /* optional per-step trace (all nullable, for tests): S = al_iter*max_newton steps */
@@ -76,8 +79,12 @@ typedef struct AlqpTrace {
 int alqp_supported(const AlqpDims *dims, int is_f64);
 /* LDS bytes one workgroup of the fused kernel uses (0 if unsupported). */
 size_t alqp_lds_bytes(const AlqpDims *dims, int is_f64);
-/* QP instances one 64-lane wavefront solves concurrently. */
+/* QP instances one 64-lane wavefront solves concurrently (team variant). */
 int alqp_qps_per_wave(const AlqpDims *dims, int is_f64);
+/* Bytes of device workspace the quad variant of alqp_solve_lin needs for these dims
+ * (0 if (nx,nu) is not instantiated). The caller allocates; contents need not be kept
+ * between calls. */
+size_t alqp_workspace_bytes(const AlqpDims *dims, int is_f64);
 
 /*
  * Fused solve on affine ("LinDx") dynamics x_{t+1} = F_t [x_t;u_t] + c_t.
@@ -91,17 +98,21 @@ int alqp_qps_per_wave(const AlqpDims *dims, int is_f64);
  *           sums, al_utils.py:552), info[B] (0 or stage*n+pivot+1 of the first
  *           non-positive pivot), status[B] (1 = iterate finite, al_utils.py:545-549),
  *           factor_out (nullable), trace (nullable)
+ *   workspace: device scratch of >= alqp_workspace_bytes() for the quad variant (nullable
+ *           -> team variant)
  */
 int alqp_solve_lin_f32(const AlqpDims *dims, const AlqpParams *prm, const void *Qd, const void *q,
                        const void *F, const void *c, const void *x0, const void *u_lo,
                        const void *u_hi, long sb_u, long st_u, void *z, void *lam, void *rho,
                        void *phi, void *rnorm2, int *info, unsigned char *status,
-                       void *factor_out, const AlqpTrace *trace, void *stream);
+                       void *factor_out, const AlqpTrace *trace, void *workspace, size_t ws_bytes,
+                       void *stream);
 int alqp_solve_lin_f64(const AlqpDims *dims, const AlqpParams *prm, const void *Qd, const void *q,
                        const void *F, const void *c, const void *x0, const void *u_lo,
                        const void *u_hi, long sb_u, long st_u, void *z, void *lam, void *rho,
                        void *phi, void *rnorm2, int *info, unsigned char *status,
-                       void *factor_out, const AlqpTrace *trace, void *stream);
+                       void *factor_out, const AlqpTrace *trace, void *workspace, size_t ws_bytes,
+                       void *stream);
 
 /*
  * One Newton direction for the nonlinear-caller mode: the caller evaluated

@@ -33,7 +33,7 @@ class OracleBackend:
 
     def solve_lin(self, dims, Qd, q, F, c, x0, ulo, uhi, sb_u, st_u, z, lam, rho, phi, rnorm2=None,
                   info=None, status=None, factor=None, al_iter=2, max_newton=4, n_ls=20, flags=3,
-                  rho_scale=10.0, trace=None):
+                  rho_scale=10.0, trace=None, variant=None):
         B, T, nx, nu = dims
         s = _sfx(z)
         npdt = np.float64 if s == "f64" else np.float32

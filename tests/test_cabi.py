@@ -19,7 +19,7 @@ def test_library_exports_every_declared_symbol():
     from deq_mpc_corl_amd import _lib
     lib = _lib.load()
     syms = declared_symbols()
-    assert len(syms) >= 16
+    assert len(syms) >= 17
     for s in syms:
         assert hasattr(lib, s), s
     assert sorted(syms) == sorted(_lib.EXPORTED_SYMBOLS)
@@ -41,20 +41,24 @@ def test_supported_dims_and_lds_budget():
     assert 0 < lib.alqp_lds_bytes(C.byref(d), 0) <= 160 * 1024
     assert lib.alqp_qps_per_wave(C.byref(d), 0) == 1
     assert lib.alqp_qps_per_wave(C.byref(_lib.AlqpDims(1, 5, 2, 1)), 0) == 4
+    # quad variant workspace: one record per (instance, stage)
+    w = lib.alqp_workspace_bytes(C.byref(_lib.AlqpDims(16384, 20, 13, 4)), 0)
+    assert w == 16384 * 20 * 292 * 4
+    assert lib.alqp_workspace_bytes(C.byref(_lib.AlqpDims(4, 20, 7, 3)), 0) == 0
 
 
 def test_bad_arguments_are_rejected_without_a_launch():
     from deq_mpc_corl_amd import _lib
     lib = _lib.load()
     d = _lib.AlqpDims(4, 20, 13, 4)
-    p = _lib.AlqpParams(2, 4, 20, 3, 10.0)
-    rc = lib.alqp_solve_lin_f32(C.byref(d), C.byref(p), *([None] * 7), 0, 0, *([None] * 8), None, None)
+    p = _lib.AlqpParams(2, 4, 20, 3, 10.0, 0)
+    rc = lib.alqp_solve_lin_f32(C.byref(d), C.byref(p), *([None] * 7), 0, 0, *([None] * 8), None, None, 0, None)
     assert rc == -1
     rc = lib.alqp_backward_f64(C.byref(d), *([None] * 8))
     assert rc == -1
     fake = C.c_void_p(16)
-    bad = _lib.AlqpParams(2, 4, 21, 3, 10.0)  # n_ls > 20
-    rc = lib.alqp_solve_lin_f32(C.byref(d), C.byref(bad), *([fake] * 7), 0, 0, *([fake] * 8), None, None)
+    bad = _lib.AlqpParams(2, 4, 21, 3, 10.0, 0)  # n_ls > 20
+    rc = lib.alqp_solve_lin_f32(C.byref(d), C.byref(bad), *([fake] * 7), 0, 0, *([fake] * 8), None, None, 0, None)
     assert rc == -1
     d2 = _lib.AlqpDims(4, 20, 7, 3)
 
