@@ -194,7 +194,7 @@ __global__ __launch_bounds__(64, 2) void k_solve_lin(SolveArgs<real> a, TraceArg
 
 // ---- fused LinDx solve, quad variant (4 lanes per instance, HBM workspace) --------------
 template <typename real, int NX, int NU, bool TRACE>
-__global__ __launch_bounds__(64, 1) void k_solve_lin_quad(SolveArgs<real> a, TraceArgs<real> tr, real *ws) {
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_solve_lin_quad(SolveArgs<real> a, TraceArgs<real> tr, real *ws) {
     using C = QCfg<real, NX, NU>;
     constexpr int N = C::N;
     const int lane = threadIdx.x, qi = lane >> 2;

@@ -144,12 +144,12 @@ struct Quad {
     real rho;
     int info;
 
-    __device__ real uhi(int t, int j) const { return guhi[t * st_u + j]; }
-    __device__ real ulo(int t, int j) const { return gulo[t * st_u + j]; }
-    __device__ real *recp(int t) const { return rec + (size_t)t * RECW; }
+    __device__ __forceinline__ real uhi(int t, int j) const { return guhi[t * st_u + j]; }
+    __device__ __forceinline__ real ulo(int t, int j) const { return gulo[t * st_u + j]; }
+    __device__ __forceinline__ real *recp(int t) const { return rec + (size_t)t * RECW; }
 
     // F_t rows of this lane: row 4s+q (zeros for rows >= NX)
-    __device__ void load_F_rows(int t, real (&W)[SW][N]) const {
+    __device__ __forceinline__ void load_F_rows(int t, real (&W)[SW][N]) const {
         const real *Fg = gF + (size_t)t * NX * N;
 #pragma unroll
         for (int s = 0; s < SW; ++s) {
@@ -164,7 +164,7 @@ struct Quad {
     }
 
     // equality residuals of all stages at the current z -> workspace (kernel start)
-    __device__ void residual_pass() {
+    __device__ __forceinline__ void residual_pass() {
         for (int t = 0; t < T - 1; ++t) {
             real W[SW][N], zt[N];
             load_F_rows(t, W);
@@ -188,7 +188,7 @@ struct Quad {
     }
 
     // ---- forward sweep: gradient, factorisation, forward substitution ------------------
-    __device__ void forward(real *g_out) {
+    __device__ __forceinline__ void forward(real *g_out) {
         real S[ST], Sy[SW];
         real vprev[NX], Syrep[NX];
 #pragma unroll
@@ -366,7 +366,7 @@ struct Quad {
     }
 
     // ---- backward sweep ---------------------------------------------------------------
-    __device__ void backward() {
+    __device__ __forceinline__ void backward() {
         real dxn[NX];
 #pragma unroll
         for (int j = 0; j < NX; ++j) dxn[j] = 0;
@@ -449,7 +449,7 @@ struct Quad {
 
     // ---- merit of K candidates (see Team::merit_candidates for the algebra) ---------------
     template <int K>
-    __device__ void merit_candidates(real (&phi)[K], bool at_z) {
+    __device__ __forceinline__ void merit_candidates(real (&phi)[K], bool at_z) {
         real c0 = 0, c1 = 0, c2 = 0;
         real acc[K];
 #pragma unroll
@@ -504,7 +504,7 @@ struct Quad {
     }
 
     // z += alpha d ; r += alpha s   (own elements only)
-    __device__ void apply_step(real alpha) {
+    __device__ __forceinline__ void apply_step(real alpha) {
         if (!active) return;
         for (int t = 0; t < T; ++t) {
             real *rp = recp(t);
@@ -521,7 +521,7 @@ struct Quad {
         }
     }
 
-    __device__ real rplus2(int &bad) {
+    __device__ __forceinline__ real rplus2(int &bad) {
         real acc = 0;
         for (int t = 0; t < T; ++t) {
             const real *rp = recp(t);
@@ -548,7 +548,7 @@ struct Quad {
     }
 
     // lam <- lam + rho r ; lam_ineq <- max(0, .)   (AL_mpc.py:316-317)
-    __device__ void dual_update() {
+    __device__ __forceinline__ void dual_update() {
         if (!active) return;
         for (int t = 0; t < T; ++t) {
             const real *rp = recp(t);
