@@ -277,6 +277,19 @@ struct Quad {
 #pragma unroll
                 for (int c = 0; c < 4; ++c)
                     if (4 * s + c < N) H[C::hidx(s, 4 * s + c)] = (q == c) ? D[4 * s + c] : real(0);
+            // minus the Schur complement of stage t-1 (its registers are dead afterwards: keeps
+            // the F'F phase below within the 256 architectural VGPRs)
+            if (t > 0) {
+#pragma unroll
+                for (int s = 0; s < SW; ++s)
+#pragma unroll
+                    for (int b = 0; b < 4 * s + 4; ++b)
+                        if (b < NX) H[C::hidx(s, b)] -= S[C::hidx(s, b)];
+            }
+#pragma unroll
+            for (int i = 0; i < ST; ++i) S[i] = 0;
+#pragma unroll
+            for (int s = 0; s < SW; ++s) Sy[s] = 0;
             // W <- -rho F_t  (the F'F term is then (1/rho) W'W)
 #pragma unroll
             for (int s = 0; s < SW; ++s)
@@ -300,17 +313,6 @@ struct Quad {
                     }
                 }
             }
-            if (t > 0) {
-#pragma unroll
-                for (int s = 0; s < SW; ++s)
-#pragma unroll
-                    for (int b = 0; b < 4 * s + 4; ++b)
-                        if (b < NX) H[C::hidx(s, b)] -= S[C::hidx(s, b)];
-            }
-#pragma unroll
-            for (int i = 0; i < ST; ++i) S[i] = 0;
-#pragma unroll
-            for (int s = 0; s < SW; ++s) Sy[s] = 0;
             // ---- right-looking panel factorisation
 #pragma unroll
             for (int j = 0; j < N; ++j) {
