@@ -120,10 +120,19 @@ struct QCfg {
     static constexpr int HT = 2 * SH * (SH + 1);  // registers of the trimmed H panel: slot s has 4(s+1) columns
     __host__ __device__ static constexpr int hidx(int s, int j) { return 2 * s * (s + 1) + j; }
     static constexpr int ST = 2 * SW * (SW + 1);  // same trimming for the Schur accumulator
-    // workspace record of one (instance, stage), in reals
-    static constexpr int LCH = SH * (SH + 1) / 2;  // 4-word chunks of L per lane
+    // workspace record of one (instance, stage), in reals. L: slot s is s+1 chunks of 4 words
+    // per lane, the lanes of a quad interleaved (64 contiguous bytes per chunk); in the last
+    // slot only the NLAST lanes that own a real row store anything.
+    static constexpr int NLAST = N - 4 * (SH - 1);                       // valid rows of the last slot (1..4)
+    __host__ __device__ static constexpr int lanes_of(int s) { return s == SH - 1 ? NLAST : 4; }
+    __host__ __device__ static constexpr int lbase(int s) {             // word offset of slot s
+        int o = 0;
+        for (int i = 0; i < s; ++i) o += (i + 1) * 4 * lanes_of(i);
+        return o;
+    }
+    static constexpr int LW = lbase(SH);
     static constexpr int oL = 0;
-    static constexpr int oY = oL + LCH * 16;       // y_t, later d_t : element k at oY + k
+    static constexpr int oY = oL + ((LW + 3) & ~3);  // y_t, later d_t : element k at oY + k
     static constexpr int oR = oY + 4 * SY;         // r_t (eq residual of row block t): row r at oR + r
     static constexpr int oS = oR + 4 * SW;         // s_t = (J d)_eq
     static constexpr int RECW = oS + 4 * SW;
@@ -142,25 +151,37 @@ struct Quad {
     long st_u;
     real *gz, *glam, *rec;
     real rho;
+    real pf;  // sink of the cache-line touches (kept alive, never meaningful)
     int info;
 
     __device__ __forceinline__ real uhi(int t, int j) const { return guhi[t * st_u + j]; }
     __device__ __forceinline__ real ulo(int t, int j) const { return gulo[t * st_u + j]; }
     __device__ __forceinline__ real *recp(int t) const { return rec + (size_t)t * RECW; }
 
-    // F_t rows of this lane: row 4s+q (zeros for rows >= NX)
+    // F_t rows of this lane: row 4s+q (zeros for rows >= NX). Loads are unconditional (row
+    // index clamped, result masked) so that all of a stage's loads go out in one batch:
+    // a load inside a divergent branch cannot be hoisted and costs its own round trip.
     __device__ __forceinline__ void load_F_rows(int t, real (&W)[SW][N]) const {
         const real *Fg = gF + (size_t)t * NX * N;
 #pragma unroll
         for (int s = 0; s < SW; ++s) {
             const int r = 4 * s + q;
-            if (4 * s + 3 < NX || r < NX) {
-                gload<N>(Fg + r * N, W[s]);
-            } else {
+            const int rc = (4 * s + 3 < NX) ? r : (r < NX ? r : NX - 1);
+            gload<N>(Fg + rc * N, W[s]);
+            if (4 * s + 3 >= NX) {
+                const real m = r < NX ? real(1) : real(0);
 #pragma unroll
-                for (int k = 0; k < N; ++k) W[s][k] = 0;
+                for (int k = 0; k < N; ++k) W[s][k] *= m;
             }
         }
+    }
+    // touch one word of every 64-byte line of [p, p+words): pulls next stage's inputs
+    // towards L2/L1 while this stage computes (there is one wavefront per SIMD, so memory
+    // latency is only hidden by what the wave itself has in flight)
+    __device__ __forceinline__ real touch(const real *p, int words) const {
+        real acc = 0;
+        for (int w = q * (64 / (int)sizeof(real)); w < words; w += 4 * (64 / (int)sizeof(real))) acc += p[w];
+        return acc;
     }
 
     // equality residuals of all stages at the current z -> workspace (kernel start)
@@ -215,14 +236,33 @@ struct Quad {
             real Y[N], D[N];
             real v[SW];
             real *rp = recp(t);
-            // ---- loads + residual + multiplier estimate
+            // ---- loads (one batch) + residual + multiplier estimate
             {
                 real zt[N], Qt[N], qt[N];
+                real cs[SW], zn[SW], lm[SW];
+                real lu[NU], ll[NU], bu[NU], bl[NU];
                 gload<N>(gz + t * N, zt);
                 gload<N>(gQd + t * N, Qt);
                 gload<N>(gq + t * N, qt);
-                if (dyn) load_F_rows(t, W);
-                else {
+                const int td = dyn ? t : (T > 1 ? T - 2 : 0);  // valid addresses for the last stage
+                load_F_rows(td, W);
+#pragma unroll
+                for (int s = 0; s < SW; ++s) {
+                    const int r = 4 * s + q, rc = r < NX ? r : NX - 1;
+                    cs[s] = gc[td * NX + rc];
+                    zn[s] = gz[(td + 1) * N + rc];
+                    lm[s] = glam[td * NX + rc];
+                }
+#pragma unroll
+                for (int j = 0; j < NU; ++j) {
+                    lu[j] = glam[T * NX + t * 2 * NU + j];
+                    ll[j] = glam[T * NX + t * 2 * NU + NU + j];
+                    bu[j] = uhi(t, j);
+                    bl[j] = ulo(t, j);
+                }
+                if (t + 2 < T) pf += touch(gF + (size_t)(t + 1) * NX * N, NX * N);
+                if (t + 1 < T) pf += touch(gQd + (t + 1) * N, N) + touch(gq + (t + 1) * N, N);
+                if (!dyn) {
 #pragma unroll
                     for (int s = 0; s < SW; ++s)
 #pragma unroll
@@ -231,15 +271,13 @@ struct Quad {
 #pragma unroll
                 for (int s = 0; s < SW; ++s) {
                     const int r = 4 * s + q;
-                    v[s] = 0;
-                    if (dyn && r < NX) {
-                        real xn = gc[t * NX + r];
+                    real xn = cs[s];
 #pragma unroll
-                        for (int k = 0; k < N; ++k) xn = fma_(W[s][k], zt[k], xn);
-                        real rr = gz[(t + 1) * N + r] - xn;
-                        v[s] = fma_(rho, rr, glam[t * NX + r]);
-                        if (active) rp[C::oR + r] = rr;
-                    }
+                    for (int k = 0; k < N; ++k) xn = fma_(W[s][k], zt[k], xn);
+                    const real rr = zn[s] - xn;
+                    const bool ok = dyn && r < NX;
+                    v[s] = ok ? fma_(rho, rr, lm[s]) : real(0);
+                    if (ok && active) rp[C::oR + r] = rr;
                 }
                 // ---- gradient (replicated in the 4 lanes) and diagonal of H_tt
 #pragma unroll
@@ -251,11 +289,10 @@ struct Quad {
                         d += rho;
                     } else {
                         const int ju = j - NX;
-                        real vu = zt[j] - uhi(t, ju), vl = -zt[j] + ulo(t, ju);
-                        real lu = glam[T * NX + t * 2 * NU + ju], ll = glam[T * NX + t * 2 * NU + NU + ju];
+                        real vu = zt[j] - bu[ju], vl = -zt[j] + bl[ju];
                         real au = vu >= 0 ? real(1) : real(0), al = vl >= 0 ? real(1) : real(0);
                         d = fma_(rho, au + al, d);
-                        g += fma_(rho, fmax_(vu, real(0)), lu) - fma_(rho, fmax_(vl, real(0)), ll);
+                        g += fma_(rho, fmax_(vu, real(0)), lu[ju]) - fma_(rho, fmax_(vl, real(0)), ll[ju]);
                     }
                     if (dyn) {
                         real p = 0;
@@ -352,8 +389,9 @@ struct Quad {
                 for (int s = 0; s < SH; ++s)
 #pragma unroll
                     for (int c = 0; c <= s; ++c)
-                        gst4(rp + C::oL + ((s * (s + 1)) / 2 + c) * 16 + 4 * q, H[C::hidx(s, 4 * c)],
-                             H[C::hidx(s, 4 * c + 1)], H[C::hidx(s, 4 * c + 2)], H[C::hidx(s, 4 * c + 3)]);
+                        if (C::lanes_of(s) == 4 || q < C::lanes_of(s))
+                            gst4(rp + C::oL + C::lbase(s) + c * 4 * C::lanes_of(s) + 4 * q, H[C::hidx(s, 4 * c)],
+                                 H[C::hidx(s, 4 * c + 1)], H[C::hidx(s, 4 * c + 2)], H[C::hidx(s, 4 * c + 3)]);
 #pragma unroll
                 for (int j = 0; j < N; ++j)
                     if ((j & 3) == q) rp[C::oY + j] = Y[j];
@@ -379,9 +417,12 @@ struct Quad {
 #pragma unroll
             for (int s = 0; s < SH; ++s)
 #pragma unroll
-                for (int c = 0; c <= s; ++c)
-                    gld4(rp + C::oL + ((s * (s + 1)) / 2 + c) * 16 + 4 * q, H[C::hidx(s, 4 * c)],
+                for (int c = 0; c <= s; ++c) {
+                    // lanes without a real row re-read lane 0's words (unconditional load, values unused)
+                    const int ql = (C::lanes_of(s) == 4 || q < C::lanes_of(s)) ? q : 0;
+                    gld4(rp + C::oL + C::lbase(s) + c * 4 * C::lanes_of(s) + 4 * ql, H[C::hidx(s, 4 * c)],
                          H[C::hidx(s, 4 * c + 1)], H[C::hidx(s, 4 * c + 2)], H[C::hidx(s, 4 * c + 3)]);
+                }
             real yo[SY];
 #pragma unroll
             for (int m = 0; m < SY; ++m) yo[m] = (4 * m + q < N) ? rp[C::oY + 4 * m + q] : real(0);
@@ -389,6 +430,11 @@ struct Quad {
 #pragma unroll
             for (int j = 0; j < N; ++j) Y[j] = qbv(yo[j >> 2], j);
             real W[SW][N];
+            load_F_rows(dyn ? t : (T > 1 ? T - 2 : 0), W);  // same batch as the record loads
+            if (t > 0) {
+                pf += touch(recp(t - 1), C::oY + 4 * SY);
+                if (t > 1) pf += touch(gF + (size_t)(t - 1) * NX * N, NX * N);
+            }
             real dxs[SW];
 #pragma unroll
             for (int s = 0; s < SW; ++s)
@@ -396,7 +442,6 @@ struct Quad {
                               (4 * s + 2 < NX) ? dxn[(4 * s + 2 < NX) ? 4 * s + 2 : 0] : real(0),
                               (4 * s + 3 < NX) ? dxn[(4 * s + 3 < NX) ? 4 * s + 3 : 0] : real(0), q);
             if (dyn) {
-                load_F_rows(t, W);
                 // v = F_t' dx_{t+1}
                 real vv[N];
 #pragma unroll
@@ -450,48 +495,71 @@ struct Quad {
     }
 
     // ---- merit of K candidates (see Team::merit_candidates for the algebra) ---------------
+    // All loads of a stage are unconditional (clamped indices, masked contributions) so they
+    // leave in one batch.
     template <int K>
     __device__ __forceinline__ void merit_candidates(real (&phi)[K], bool at_z) {
         real c0 = 0, c1 = 0, c2 = 0;
         real acc[K];
 #pragma unroll
         for (int k = 0; k < K; ++k) acc[k] = 0;
+        constexpr int MU0 = NX / 4;  // first element slot that can hold a control
         for (int t = 0; t < T; ++t) {
             const real *rp = recp(t);
+            real zz[SY], dd[SY], QQ[SY], qq[SY];
+            real rv[SW], sv[SW], lv[SW];
+            real lu[SY], ll[SY], bu[SY], bl[SY];
+#pragma unroll
+            for (int m = 0; m < SY; ++m) {
+                const int j = 4 * m + q, jc = (4 * m + 3 < N) ? j : (j < N ? j : N - 1);
+                zz[m] = gz[t * N + jc];
+                dd[m] = rp[C::oY + jc];
+                QQ[m] = gQd[t * N + jc];
+                qq[m] = gq[t * N + jc];
+                if (m >= MU0) {
+                    const int ju = jc >= NX ? jc - NX : 0;
+                    lu[m] = glam[T * NX + t * 2 * NU + ju];
+                    ll[m] = glam[T * NX + t * 2 * NU + NU + ju];
+                    bu[m] = uhi(t, ju);
+                    bl[m] = ulo(t, ju);
+                }
+            }
+#pragma unroll
+            for (int s = 0; s < SW; ++s) {
+                const int r = 4 * s + q, rc = (4 * s + 3 < NX) ? r : (r < NX ? r : NX - 1);
+                rv[s] = rp[C::oR + rc];
+                sv[s] = rp[C::oS + rc];
+                lv[s] = glam[t * NX + rc];
+            }
 #pragma unroll
             for (int m = 0; m < SY; ++m) {
                 const int j = 4 * m + q;
-                if (4 * m + 3 < N || j < N) {
-                    real z = gz[t * N + j], d = at_z ? real(0) : rp[C::oY + j];
-                    real Qv = gQd[t * N + j], qv = gq[t * N + j];
-                    c0 = fma_(fma_(real(0.5) * Qv, z, qv), z, c0);
-                    c1 = fma_(fma_(Qv, z, qv), d, c1);
-                    c2 = fma_(real(0.5) * Qv * d, d, c2);
-                    if (j >= NX) {
-                        const int ju = j - NX;
-                        real lu = glam[T * NX + t * 2 * NU + ju], ll = glam[T * NX + t * 2 * NU + NU + ju];
-                        real bu = uhi(t, ju), bl = ulo(t, ju);
-                        real alpha = 1;
+                const real ok = (4 * m + 3 < N || j < N) ? real(1) : real(0);
+                const real z = zz[m], d = at_z ? real(0) : dd[m] * ok, Qv = QQ[m] * ok, qv = qq[m] * ok;
+                c0 = fma_(fma_(real(0.5) * Qv, z, qv), z, c0);
+                c1 = fma_(fma_(Qv, z, qv), d, c1);
+                c2 = fma_(real(0.5) * Qv * d, d, c2);
+                if (m >= MU0) {
+                    const real isu = (j >= NX && j < N) ? real(1) : real(0);
+                    real alpha = 1;
 #pragma unroll
-                        for (int k = 0; k < K; ++k) {
-                            real zk = fma_(alpha, d, z);
-                            real vu = zk - bu, vl = bl - zk;
-                            real cu = fmax_(vu, real(0)), cl = fmax_(vl, real(0));
-                            acc[k] += fma_(lu, vu, ll * vl) + real(0.5) * rho * fma_(cu, cu, cl * cl);
-                            alpha *= real(0.5);
-                        }
+                    for (int k = 0; k < K; ++k) {
+                        real zk = fma_(alpha, d, z);
+                        real vu = zk - bu[m], vl = bl[m] - zk;
+                        real cu = fmax_(vu, real(0)), cl = fmax_(vl, real(0));
+                        acc[k] = fma_(isu, fma_(lu[m], vu, ll[m] * vl) + real(0.5) * rho * fma_(cu, cu, cl * cl), acc[k]);
+                        alpha *= real(0.5);
                     }
                 }
             }
 #pragma unroll
             for (int s = 0; s < SW; ++s) {
                 const int r = 4 * s + q;
-                if (4 * s + 3 < NX || r < NX) {
-                    real rr = rp[C::oR + r], sv = at_z ? real(0) : rp[C::oS + r], lm = glam[t * NX + r];
-                    c0 = fma_(fma_(real(0.5) * rho, rr, lm), rr, c0);
-                    c1 = fma_(fma_(rho, rr, lm), sv, c1);
-                    c2 = fma_(real(0.5) * rho * sv, sv, c2);
-                }
+                const real ok = (4 * s + 3 < NX || r < NX) ? real(1) : real(0);
+                const real rr = rv[s] * ok, ss = at_z ? real(0) : sv[s] * ok, lm = lv[s] * ok;
+                c0 = fma_(fma_(real(0.5) * rho, rr, lm), rr, c0);
+                c1 = fma_(fma_(rho, rr, lm), ss, c1);
+                c2 = fma_(real(0.5) * rho * ss, ss, c2);
             }
         }
         c0 = qsum(c0);
