@@ -23,6 +23,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 GB/s achievable copy
+KERNEL_OF = {"team": "k_solve_lin", "quad": "k_solve_lin_quad"}
 
 
 def words_per_solve(T, nx, nu):
@@ -112,6 +113,7 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 
+    variant = args.variant if args.variant != "auto" else "quad"  # what backend 'auto' resolves to here
     if rank == 0:
         value = world * B * args.steps / elapsed
         sz = 4 if args.dtype == "f32" else 8
@@ -122,7 +124,7 @@ def main():
         if os.path.exists(prof):
             try:
                 rec = json.load(open(prof))
-                key = f"{args.dtype}_B{B}_T{T}_nx{nx}_nu{nu}"
+                key = f"{variant}_{args.dtype}_B{B}_T{T}_nx{nx}_nu{nu}"
                 traffic = rec.get(key, {}).get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
@@ -134,13 +136,17 @@ def main():
             "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": f"rex_quadrotor-shaped (nx={nx},nu={nu}) T={T} B={B}/GPU fused AL solve, "
                                    f"al_iter={args.al_iter}x4 Newton, 20-pt line search, exit_mode=fixed",
-                       "global_batch": world * B, "parallelism": f"batch-sharded x{world}, no data-path collective"},
+                       "global_batch": world * B, "parallelism": f"batch-sharded x{world}, no data-path collective",
+                       "kernel_variant": variant},
             "all_instances_ok": ok,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "k_solve_lin", "kernel_ms": kernel_ms,
+                         "kernel": KERNEL_OF[variant], "kernel_ms": kernel_ms,
                          "algorithmic_bytes_per_launch": alg_bytes,
-                         "note": "fused solve is VALU/LDS-latency bound (AI ~75 flop/B), see DESIGN.md"},
+                         "note": "achieved = algorithmic bytes / kernel time (BASELINE metric). The quad kernel "
+                                 "deliberately streams its per-stage factor through an HBM workspace: 'traffic' "
+                                 "is the measured HBM volume per launch (rocprofv3 FETCH_SIZE*2+WRITE_SIZE), "
+                                 "see DESIGN.md section 5"},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, T, nx, nu)
@@ -158,7 +164,17 @@ def cpu_baseline(args, T, nx, nu):
     from oracle import oracle_py as orc
 
     dt = torch.float32 if args.dtype == "f32" else torch.float64
-    threads = orc.max_threads()
+    # use the cores this process may actually run on (the GPU box gives a 1-GPU job a CPU
+    # share; OpenMP's default of one thread per host core oversubscribes it badly)
+    avail = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            avail = min(avail, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    threads = max(1, min(orc.max_threads(), avail, 16))
+    orc.set_threads(threads)
     Bs = 2048
     p = synthetic_problem(Bs, T, nx, nu, seed=0, dtype=dt)
     c = lambda a: a.numpy()

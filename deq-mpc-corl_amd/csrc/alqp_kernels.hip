@@ -219,7 +219,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     qd.glam = a.lam + (size_t)b * M;
     qd.rec = ws + (size_t)b * T * C::RECW;
     qd.rho = a.rho[b];
-    qd.pf = 0;
     qd.info = 0;
     real phi_prev = a.phi[b];
     qd.residual_pass();
@@ -280,7 +279,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     if (active && qd.q == 0) {
         a.rho[b] = qd.rho;
         a.phi[b] = phi_prev;
-        if (a.rnorm2) a.rnorm2[b] = (qd.pf == real(-1.2345e30)) ? real(0) : rn2;  // keeps the touches alive
+        if (a.rnorm2) a.rnorm2[b] = rn2;
         if (a.info) a.info[b] = qd.info;
         if (a.status) a.status[b] = bad ? 0 : 1;
     }

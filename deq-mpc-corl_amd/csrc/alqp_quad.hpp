@@ -151,7 +151,6 @@ struct Quad {
     long st_u;
     real *gz, *glam, *rec;
     real rho;
-    real pf;  // sink of the cache-line touches (kept alive, never meaningful)
     int info;
 
     __device__ __forceinline__ real uhi(int t, int j) const { return guhi[t * st_u + j]; }
@@ -175,15 +174,6 @@ struct Quad {
             }
         }
     }
-    // touch one word of every 64-byte line of [p, p+words): pulls next stage's inputs
-    // towards L2/L1 while this stage computes (there is one wavefront per SIMD, so memory
-    // latency is only hidden by what the wave itself has in flight)
-    __device__ __forceinline__ real touch(const real *p, int words) const {
-        real acc = 0;
-        for (int w = q * (64 / (int)sizeof(real)); w < words; w += 4 * (64 / (int)sizeof(real))) acc += p[w];
-        return acc;
-    }
-
     // equality residuals of all stages at the current z -> workspace (kernel start)
     __device__ __forceinline__ void residual_pass() {
         for (int t = 0; t < T - 1; ++t) {
@@ -260,8 +250,6 @@ struct Quad {
                     bu[j] = uhi(t, j);
                     bl[j] = ulo(t, j);
                 }
-                if (t + 2 < T) pf += touch(gF + (size_t)(t + 1) * NX * N, NX * N);
-                if (t + 1 < T) pf += touch(gQd + (t + 1) * N, N) + touch(gq + (t + 1) * N, N);
                 if (!dyn) {
 #pragma unroll
                     for (int s = 0; s < SW; ++s)
@@ -431,10 +419,6 @@ struct Quad {
             for (int j = 0; j < N; ++j) Y[j] = qbv(yo[j >> 2], j);
             real W[SW][N];
             load_F_rows(dyn ? t : (T > 1 ? T - 2 : 0), W);  // same batch as the record loads
-            if (t > 0) {
-                pf += touch(recp(t - 1), C::oY + 4 * SY);
-                if (t > 1) pf += touch(gF + (size_t)(t - 1) * NX * N, NX * N);
-            }
             real dxs[SW];
 #pragma unroll
             for (int s = 0; s < SW; ++s)
