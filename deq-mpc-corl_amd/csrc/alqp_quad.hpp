@@ -488,7 +488,8 @@ struct Quad {
 #pragma unroll
         for (int k = 0; k < K; ++k) acc[k] = 0;
         constexpr int MU0 = NX / 4;  // first element slot that can hold a control
-        for (int t = 0; t < T; ++t) {
+#pragma unroll 4
+        for (int t = 0; t < T; ++t) {  // 4 stages of loads in flight per round trip
             const real *rp = recp(t);
             real zz[SY], dd[SY], QQ[SY], qq[SY];
             real rv[SW], sv[SW], lv[SW];
@@ -560,17 +561,33 @@ struct Quad {
     // z += alpha d ; r += alpha s   (own elements only)
     __device__ __forceinline__ void apply_step(real alpha) {
         if (!active) return;
+        real *__restrict__ zp = gz;       // z and the workspace never overlap: lets the loads of
+        real *__restrict__ wp = rec;      // several stages leave before the first store
+#pragma unroll 4
         for (int t = 0; t < T; ++t) {
-            real *rp = recp(t);
+            real *__restrict__ rp = wp + (size_t)t * RECW;
+            real zz[SY], dd[SY], rr[SW], ss[SW];
+#pragma unroll
+            for (int m = 0; m < SY; ++m) {
+                const int j = 4 * m + q, jc = j < N ? j : N - 1;
+                zz[m] = zp[t * N + jc];
+                dd[m] = rp[C::oY + jc];
+            }
+#pragma unroll
+            for (int s = 0; s < SW; ++s) {
+                const int r = 4 * s + q, rc = r < NX ? r : NX - 1;
+                rr[s] = rp[C::oR + rc];
+                ss[s] = rp[C::oS + rc];
+            }
 #pragma unroll
             for (int m = 0; m < SY; ++m) {
                 const int j = 4 * m + q;
-                if (j < N) gz[t * N + j] = fma_(alpha, rp[C::oY + j], gz[t * N + j]);
+                if (j < N) zp[t * N + j] = fma_(alpha, dd[m], zz[m]);
             }
 #pragma unroll
             for (int s = 0; s < SW; ++s) {
                 const int r = 4 * s + q;
-                if (r < NX) rp[C::oR + r] = fma_(alpha, rp[C::oS + r], rp[C::oR + r]);
+                if (r < NX) rp[C::oR + r] = fma_(alpha, ss[s], rr[s]);
             }
         }
     }
