@@ -134,7 +134,8 @@ def main():
             "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / max(args.steps, 1),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": f"rex_quadrotor-shaped (nx={nx},nu={nu}) T={T} B={B}/GPU fused AL solve, "
+            "config": {"workload": f"{ {(2, 1): 'pendulum', (8, 2): 'flying_cartpole2d', (13, 4): 'rex_quadrotor'}.get((nx, nu), 'synthetic') }"
+                                   f"-shaped (nx={nx},nu={nu}) T={T} B={B}/GPU fused AL solve, "
                                    f"al_iter={args.al_iter}x4 Newton, 20-pt line search, exit_mode=fixed",
                        "global_batch": world * B, "parallelism": f"batch-sharded x{world}, no data-path collective",
                        "kernel_variant": variant},

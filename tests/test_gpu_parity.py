@@ -299,3 +299,61 @@ def test_every_compiled_dims_vs_oracle(nx, nu, dtype, variant):
     assert ok.sum() >= 0.7 * B
     assert np.abs(c(z) - o["z"])[ok].max() < tol
     assert np.abs(c(lam) - o["lam"])[ok].max() < tol * 20
+
+
+@pytest.mark.parametrize("variant", ["team", "quad"])
+def test_long_horizon_T50(variant):
+    """BASELINE config 5 shape (nx=13, nu=4, T=50): a small batch against the oracle, fp32 and fp64."""
+    from deq_mpc_corl_amd import synthetic_problem
+    from deq_mpc_corl_amd.backend import default_backend
+    be = default_backend()
+    for dtype in ("f64", "f32"):
+        dt = TD[dtype]
+        B, T, nx, nu = 33, 50, 13, 4
+        p = synthetic_problem(B, T, nx, nu, seed=9, dtype=dt, device=DEV)
+        M = T * nx + 2 * T * nu
+        z = p.z0.clone()
+        lam = torch.zeros(B, M, dtype=dt, device=DEV)
+        rho = torch.ones(B, dtype=dt, device=DEV)
+        phi = torch.zeros(B, dtype=dt, device=DEV)
+        rn2 = torch.zeros(B, dtype=dt, device=DEV)
+        info = torch.zeros(B, dtype=torch.int32, device=DEV)
+        st = torch.zeros(B, dtype=torch.uint8, device=DEV)
+        be.solve_lin((B, T, nx, nu), p.Qd, p.q, p.F, p.c, p.x0, p.u_lo, p.u_hi, 0, 0, z, lam, rho, phi, rn2,
+                     info, st, al_iter=2, max_newton=4, n_ls=20, flags=3, variant=variant)
+        torch.cuda.synchronize()
+        c = lambda a: a.cpu().numpy()
+        o = orc.solve_lin(dtype, c(p.Qd), c(p.q), c(p.F), c(p.c), c(p.x0), c(p.u_lo), c(p.u_hi), c(p.z0),
+                          al_iter=2, exit_mode="fixed", trace_steps=8)
+        ok = ~near_tie_instances(o, dtype)
+        assert int(info.abs().sum()) == 0 and ok.sum() >= 0.7 * B
+        assert np.abs(c(z) - o["z"])[ok].max() < (1e-9 if dtype == "f64" else 3e-3)
+
+
+def test_variants_agree_at_headline_size():
+    """team and quad kernels on the full benchmark batch: same answers up to fp32 rounding
+    on all but the few instances where a line-search near-tie resolves differently."""
+    from deq_mpc_corl_amd import synthetic_problem
+    from deq_mpc_corl_amd.backend import default_backend
+    be = default_backend()
+    B, T, nx, nu = 16384, 20, 13, 4
+    dt = torch.float32
+    p = synthetic_problem(B, T, nx, nu, seed=0, dtype=dt, device=DEV)
+    M = T * nx + 2 * T * nu
+    res = {}
+    for variant in ("team", "quad"):
+        z = p.z0.clone()
+        lam = torch.zeros(B, M, dtype=dt, device=DEV)
+        rho = torch.ones(B, dtype=dt, device=DEV)
+        phi = torch.zeros(B, dtype=dt, device=DEV)
+        rn2 = torch.zeros(B, dtype=dt, device=DEV)
+        info = torch.zeros(B, dtype=torch.int32, device=DEV)
+        st = torch.zeros(B, dtype=torch.uint8, device=DEV)
+        be.solve_lin((B, T, nx, nu), p.Qd, p.q, p.F, p.c, p.x0, p.u_lo, p.u_hi, 0, 0, z, lam, rho, phi, rn2,
+                     info, st, al_iter=2, max_newton=4, n_ls=20, flags=3, variant=variant)
+        torch.cuda.synchronize()
+        assert int(info.abs().sum()) == 0 and int(st.sum()) == B
+        res[variant] = z
+    err = (res["team"] - res["quad"]).abs().amax(dim=(1, 2))
+    assert float((err < 1e-3).float().mean()) > 0.97
+    assert float(err.median()) < 2e-5
