@@ -1,0 +1,141 @@
+"""GPU edge cases of the hot path, both kernel variants: per-(b,t) bounds through the
+stride arguments, minimum horizon / single instance, non-finite input and indefinite
+Hessian reported per instance without disturbing the neighbours, fewer line-search
+candidates, and equivalence of one fused launch with the same work split over launches."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import oracle_py as orc
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+VARIANTS = ["team", "quad"]
+
+
+def solve(p, dt, variant, al_iter=2, max_newton=4, n_ls=20, flags=3, ulo=None, uhi=None, sb=0, st=0,
+          z=None, lam=None, rho=None, phi=None):
+    from deq_mpc_corl_amd.backend import default_backend
+    be = default_backend()
+    B, T, nx, nu = p.B, p.T, p.nx, p.nu
+    M = T * nx + 2 * T * nu
+    z = p.z0.clone() if z is None else z
+    lam = torch.zeros(B, M, dtype=dt, device=DEV) if lam is None else lam
+    rho = torch.ones(B, dtype=dt, device=DEV) if rho is None else rho
+    phi = torch.zeros(B, dtype=dt, device=DEV) if phi is None else phi
+    rn2 = torch.zeros(B, dtype=dt, device=DEV)
+    info = torch.zeros(B, dtype=torch.int32, device=DEV)
+    status = torch.zeros(B, dtype=torch.uint8, device=DEV)
+    be.solve_lin((B, T, nx, nu), p.Qd, p.q, p.F, p.c, p.x0, p.u_lo if ulo is None else ulo,
+                 p.u_hi if uhi is None else uhi, sb, st, z, lam, rho, phi, rn2, info, status,
+                 al_iter=al_iter, max_newton=max_newton, n_ls=n_ls, flags=flags, variant=variant)
+    torch.cuda.synchronize()
+    return z, lam, rho, phi, rn2, info, status
+
+
+def c(a):
+    return a.cpu().numpy()
+
+
+@pytest.mark.parametrize("variant", VARIANTS)
+def test_per_instance_per_stage_bounds(variant):
+    """u_lower/u_upper of shape [B,T,nu] (the reference broadcasts whatever it is given,
+    al_utils.py:293) reach the kernels through the (sb_u, st_u) element strides."""
+    from deq_mpc_corl_amd import synthetic_problem
+    dt = torch.float64
+    B, T, nx, nu = 21, 6, 8, 2
+    p = synthetic_problem(B, T, nx, nu, seed=2, dtype=dt, device=DEV, active=True)
+    g = torch.Generator(device="cpu").manual_seed(4)
+    hi = (0.05 + 0.3 * torch.rand(B, T, nu, generator=g, dtype=dt)).to(DEV)
+    lo = -(0.05 + 0.3 * torch.rand(B, T, nu, generator=g, dtype=dt)).to(DEV)
+    z, lam, *_ = solve(p, dt, variant, ulo=lo.contiguous(), uhi=hi.contiguous(), sb=T * nu, st=nu)
+    o = orc.solve_lin("f64", c(p.Qd), c(p.q), c(p.F), c(p.c), c(p.x0), c(lo), c(hi), c(p.z0), al_iter=2,
+                      exit_mode="fixed")
+    assert np.abs(c(z) - o["z"]).max() < 1e-9
+    assert np.abs(c(lam) - o["lam"]).max() < 1e-8
+    assert float(lam[:, T * nx:].max()) > 0  # some bound multipliers became active
+
+
+@pytest.mark.parametrize("variant", VARIANTS)
+@pytest.mark.parametrize("B,T", [(1, 2), (1, 20), (17, 2)])
+def test_minimum_horizon_and_single_instance(variant, B, T):
+    from deq_mpc_corl_amd import synthetic_problem
+    dt = torch.float64
+    p = synthetic_problem(B, T, 13, 4, seed=3, dtype=dt, device=DEV)
+    z, lam, rho, *_ = solve(p, dt, variant)
+    o = orc.solve_lin("f64", c(p.Qd), c(p.q), c(p.F), c(p.c), c(p.x0), c(p.u_lo), c(p.u_hi), c(p.z0), al_iter=2,
+                      exit_mode="fixed")
+    assert np.abs(c(z) - o["z"]).max() < 1e-9
+    assert np.allclose(c(rho), 100.0)
+
+
+@pytest.mark.parametrize("variant", VARIANTS)
+def test_nonfinite_input_is_flagged_per_instance(variant):
+    """A NaN in one instance's x0 makes that instance's status 0 (al_utils.py:545-549) and
+    leaves every other instance bit-for-bit unchanged."""
+    from deq_mpc_corl_amd import synthetic_problem
+    dt = torch.float32
+    B = 40
+    p = synthetic_problem(B, 10, 8, 2, seed=6, dtype=dt, device=DEV)
+    z_ref, lam_ref, *_ , st_ref = solve(p, dt, variant)
+    assert int(st_ref.sum()) == B
+    x0 = p.x0.clone()
+    x0[7, 3] = float("nan")
+    p2 = p._replace(x0=x0)
+    z, lam, _, _, _, info, status = solve(p2, dt, variant)
+    assert int(status[7]) == 0 and int(status.sum()) == B - 1
+    keep = torch.ones(B, dtype=torch.bool, device=DEV)
+    keep[7] = False
+    assert torch.equal(z[keep], z_ref[keep]) and torch.equal(lam[keep], lam_ref[keep])
+
+
+@pytest.mark.parametrize("variant", VARIANTS)
+def test_indefinite_hessian_is_reported_in_info(variant):
+    """Negative cost weights make H indefinite for one instance: its info holds the first
+    non-positive pivot (stage*n + column + 1, like cholesky_ex's info); the rest are clean."""
+    from deq_mpc_corl_amd import synthetic_problem
+    dt = torch.float64
+    B, T, nx, nu = 24, 8, 8, 2
+    p = synthetic_problem(B, T, nx, nu, seed=8, dtype=dt, device=DEV)
+    Qd = p.Qd.clone()
+    Qd[5, 2, :] = -50.0
+    p2 = p._replace(Qd=Qd, q=-(Qd * p.xref))
+    z, lam, _, _, _, info, status = solve(p2, dt, variant, al_iter=1, max_newton=1)
+    info = c(info)
+    assert info[5] != 0 and (np.delete(info, 5) == 0).all()
+    stage, col = divmod(int(info[5]) - 1, nx + nu)
+    assert stage <= 2
+
+
+@pytest.mark.parametrize("variant", VARIANTS)
+@pytest.mark.parametrize("n_ls", [1, 5])
+def test_fewer_line_search_candidates(variant, n_ls):
+    from deq_mpc_corl_amd import synthetic_problem
+    dt = torch.float64
+    p = synthetic_problem(12, 7, 13, 4, seed=10, dtype=dt, device=DEV)
+    z, lam, *_ = solve(p, dt, variant, n_ls=n_ls)
+    o = orc.solve_lin("f64", c(p.Qd), c(p.q), c(p.F), c(p.c), c(p.x0), c(p.u_lo), c(p.u_hi), c(p.z0), al_iter=2,
+                      n_ls=n_ls, exit_mode="fixed")
+    assert np.abs(c(z) - o["z"]).max() < 1e-9
+
+
+@pytest.mark.parametrize("variant", VARIANTS)
+def test_one_launch_equals_step_by_step_launches(variant):
+    """The host-driven sequence the 'reference' exit mode uses (merit init, one Newton step per
+    launch, dual update; state carried in z/lam/rho/phi between launches) is the same
+    arithmetic as the single fused launch: results agree to rounding (the factor is rebuilt
+    from identical inputs, so in fact bit for bit)."""
+    from deq_mpc_corl_amd import synthetic_problem
+    dt = torch.float32
+    p = synthetic_problem(50, 10, 8, 2, seed=12, dtype=dt, device=DEV)
+    zf, lamf, rhof, *_ = solve(p, dt, variant, al_iter=2, max_newton=4, flags=3)
+    z, lam, rho, phi = p.z0.clone(), None, None, None
+    z, lam, rho, phi, *_ = solve(p, dt, variant, al_iter=1, max_newton=0, flags=1, z=z)
+    for it in range(2):
+        if it > 0:
+            z, lam, rho, phi, *_ = solve(p, dt, variant, al_iter=1, max_newton=0, flags=1, z=z, lam=lam, rho=rho, phi=phi)
+        for _ in range(4):
+            z, lam, rho, phi, *_ = solve(p, dt, variant, al_iter=1, max_newton=1, flags=0, z=z, lam=lam, rho=rho, phi=phi)
+        z, lam, rho, phi, *_ = solve(p, dt, variant, al_iter=1, max_newton=0, flags=2, z=z, lam=lam, rho=rho, phi=phi)
+    assert torch.allclose(z, zf, atol=1e-6) and torch.allclose(lam, lamf, atol=1e-5)
+    assert torch.equal(rho, rhof)
