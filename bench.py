@@ -54,11 +54,19 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # BENCH_DIST_BACKEND=gloo is a rehearsal switch for boxes with fewer GPUs than ranks (ranks
+    # then share devices); the driver's multi-GPU runs use the default: RCCL ("nccl") over xGMI
+    backend = os.environ.get("BENCH_DIST_BACKEND", "nccl")
+    ndev = torch.cuda.device_count()
+    dev_index = local_rank if backend == "nccl" else local_rank % max(ndev, 1)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group(backend)
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
 
     from deq_mpc_corl_amd import synthetic_problem
     from deq_mpc_corl_amd import _lib
@@ -109,9 +117,11 @@ def main():
     ok = bool((info == 0).all().item()) and bool((status == 1).all().item())
 
     if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        tmax = torch.tensor([elapsed, 0.0 if ok else 1.0], dtype=torch.float64,
+                            device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
+        elapsed = float(tmax[0].item())
+        ok = float(tmax[1].item()) == 0.0
 
     variant = args.variant if args.variant != "auto" else "quad"  # what backend 'auto' resolves to here
     if rank == 0:
