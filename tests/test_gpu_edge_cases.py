@@ -139,3 +139,33 @@ def test_one_launch_equals_step_by_step_launches(variant):
         z, lam, rho, phi, *_ = solve(p, dt, variant, al_iter=1, max_newton=0, flags=2, z=z, lam=lam, rho=rho, phi=phi)
     assert torch.allclose(z, zf, atol=1e-6) and torch.allclose(lam, lamf, atol=1e-5)
     assert torch.equal(rho, rhof)
+
+
+def test_streaming_mode_matches_cpu_host_logic():
+    """warm_start_initialize + al_solve_stream semantics (AL_mpc.py:342-423, 581-592) on the GPU
+    backend against the same host logic driven by the test-only oracle backend: lamda zeroed,
+    rho clamped, iteration stops once rho exceeds 1e8 and reports status True."""
+    from types import SimpleNamespace
+    from deq_mpc_corl_amd import MPC, AffineDynamics, QuadCost, synthetic_problem
+    from tests.oracle_backend import OracleBackend
+    dt = torch.float64
+    B, T, nx, nu = 12, 8, 8, 2
+    out = {}
+    for name, device, backend in (("hip", DEV, None), ("cpu", "cpu", OracleBackend())):
+        p = synthetic_problem(B, T, nx, nu, seed=21, dtype=dt, device=device)
+        mpc = MPC(nx, nu, T, u_lower=p.u_lo, u_upper=p.u_hi, n_batch=B, dtype=dt, backend=backend)
+        mpc.reinitialize(p.x0, None)
+        dyn = AffineDynamics(p.F, p.c)
+        cost = QuadCost(torch.diag_embed(p.Qd), p.q, torch.zeros(B, T, dtype=dt, device=device))
+        mpc.al_iter = 2
+        x, u, s0 = mpc(p.x0, cost, dyn, dyn.jac, x_init=p.z0[..., :nx].clone(), u_init=p.z0[..., nx:].clone())
+        mpc.warm_start_initialize(x.to(dt), u.to(dt), SimpleNamespace(rho_init_max=50.0))
+        mpc.al_iter = 10
+        x2, u2, s1 = mpc(p.x0, cost, dyn, dyn.jac)
+        out[name] = (x.cpu(), u.cpu(), s0, x2.cpu(), u2.cpu(), s1, mpc.rho_prev.cpu(), list(mpc.last_newton_per_al))
+    h, cc = out["hip"], out["cpu"]
+    assert h[2] is False and h[5] is True and cc[5] is True
+    assert h[7] == cc[7]
+    assert torch.allclose(h[0], cc[0], atol=1e-6) and torch.allclose(h[1], cc[1], atol=1e-6)
+    assert torch.allclose(h[3], cc[3], atol=1e-5) and torch.allclose(h[4], cc[4], atol=1e-5)
+    assert torch.equal(h[6], cc[6])
