@@ -13,7 +13,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libmi_alqp.so")
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 
 class AlqpDims(C.Structure):
@@ -52,6 +52,7 @@ _SIGS = {
     "alqp_dual_update": (C.c_int, [C.POINTER(AlqpDims), _P, _P, _P, _P, _P, C.c_long, C.c_long, _P, _P,
                                    C.c_double, _P]),
     "alqp_backward": (C.c_int, [C.POINTER(AlqpDims), _P, _P, _P, _P, _P, _P, _P, _P]),
+    "alqp_backward_ws": (C.c_int, [C.POINTER(AlqpDims), _P, C.c_size_t, _P, _P, _P, _P, _P, _P, _P]),
 }
 _PLAIN = {
     "alqp_abi_version": (C.c_int, []),

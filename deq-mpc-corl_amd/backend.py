@@ -83,8 +83,10 @@ class HipBackend:
     def solve_lin(self, dims, Qd, q, F, c, x0, ulo, uhi, sb_u, st_u, z, lam, rho, phi,
                   rnorm2=None, info=None, status=None, factor=None, al_iter=2, max_newton=4,
                   n_ls=20, flags=_lib.ALQP_INIT_MERIT | _lib.ALQP_DUAL_UPDATE, rho_scale=10.0,
-                  trace=None, variant=None):
-        """variant: None/"auto" (quad unless a factor must be saved), "team", "quad"."""
+                  trace=None, variant=None, workspace=None):
+        """variant: None/"auto" (quad unless a factor must be saved), "team", "quad".
+        workspace: a dedicated scratch tensor for the quad variant (kept by the caller when
+        the factor it holds afterwards is needed for `backward_ws`); default: a cached one."""
         B, T, nx, nu = dims
         dt = z.dtype
         sfx = _dt(z)
@@ -96,7 +98,12 @@ class HipBackend:
             vnum = 1 if (flags & _lib.ALQP_SAVE_FACTOR) else 2
         ws, ws_bytes = (None, 0)
         if vnum == 2:
-            ws, ws_bytes = self._workspace(dims, z)
+            if workspace is not None:
+                ws, ws_bytes = workspace, self.workspace_bytes(*dims, z.dtype)
+                if ws.numel() * ws.element_size() < ws_bytes:
+                    raise ValueError("mi_alqp: workspace too small")
+            else:
+                ws, ws_bytes = self._workspace(dims, z)
         p = _lib.AlqpParams(al_iter, max_newton, n_ls, flags, rho_scale, vnum)
         tr = None
         if trace is not None:
@@ -171,6 +178,23 @@ class HipBackend:
                 _ptr(z_final, "z_final", dt), _ptr(gbar, "gbar", dt), _ptr(q_grad, "q_grad", dt),
                 _ptr(Qd_grad, "Qd_grad", dt), _stream())
         _lib.check(rc, "alqp_backward_" + sfx)
+
+
+    def new_workspace(self, dims, like):
+        """A private workspace for one quad solve whose factor will be used by backward_ws."""
+        need = self.workspace_bytes(*dims, like.dtype)
+        return torch.empty(need // like.element_size() + 16, dtype=like.dtype, device=like.device)
+
+    def backward_ws(self, dims, workspace, F, rho, z_final, gbar, q_grad, Qd_grad):
+        B, T, nx, nu = dims
+        dt = gbar.dtype
+        sfx = _dt(gbar)
+        d = _lib.AlqpDims(B, T, nx, nu)
+        fn = getattr(self.lib, "alqp_backward_ws_" + sfx)
+        rc = fn(C.byref(d), _ptr(workspace, "workspace", dt), self.workspace_bytes(*dims, dt),
+                _ptr(F, "F", dt), _ptr(rho, "rho", dt), _ptr(z_final, "z_final", dt),
+                _ptr(gbar, "gbar", dt), _ptr(q_grad, "q_grad", dt), _ptr(Qd_grad, "Qd_grad", dt), _stream())
+        _lib.check(rc, "alqp_backward_ws_" + sfx)
 
 
 _default = None

@@ -285,6 +285,43 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     }
 }
 
+// ---- backward of the implicit layer, quad variant: the factor is the workspace a previous
+//      quad solve left behind (per-stage lower triangles of L) ---------------------------------
+template <typename real, int NX, int NU>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_backward_quad(BwdArgs<real> a, real *ws) {
+    using C = QCfg<real, NX, NU>;
+    constexpr int N = C::N;
+    const int lane = threadIdx.x, qi = lane >> 2;
+    const int b_raw = blockIdx.x * 16 + qi;
+    const bool active = b_raw < a.B;
+    const int b = active ? b_raw : a.B - 1;
+    const int T = a.T;
+    Quad<real, NX, NU> qd;
+    qd.q = lane & 3;
+    qd.T = T;
+    qd.active = active;
+    qd.gF = a.F + (size_t)b * (T - 1) * NX * N;
+    qd.gQd = nullptr; qd.gq = nullptr; qd.gc = nullptr; qd.gx0 = nullptr; qd.gulo = nullptr; qd.guhi = nullptr;
+    qd.st_u = 0;
+    qd.gz = nullptr; qd.glam = nullptr;
+    qd.rec = ws + (size_t)b * T * C::RECW;
+    qd.rho = a.rho[b];
+    qd.info = 0;
+    qd.solve_forward(a.gbar + (size_t)b * T * N);
+    qd.backward();
+    if (active) {
+        const real *zf = a.z_final + (size_t)b * T * N;
+        real *qg = a.q_grad + (size_t)b * T * N;
+        real *Qg = a.Qd_grad + (size_t)b * T * N;
+        for (int t = 0; t < T; ++t)
+            for (int j = qd.q; j < N; j += 4) {
+                const real w = qd.recp(t)[C::oY + j];
+                qg[t * N + j] = w;
+                Qg[t * N + j] = w * zf[t * N + j];
+            }
+    }
+}
+
 // ---- one Newton direction (nonlinear-caller mode) ----------------------------------
 template <typename real, int NX, int NU>
 __global__ __launch_bounds__(64) void k_newton_step(StepArgs<real> a) {
@@ -553,6 +590,15 @@ size_t quad_ws_bytes(int nx, int nu, int B, int T) {
 }
 
 template <typename real>
+int dispatch_backward_quad(int nx, int nu, const BwdArgs<real> &a, real *ws, hipStream_t stream) {
+#define X(NX, NU) \
+    if (nx == NX && nu == NU) return launch_quad_kernel<real, NX, NU>(k_backward_quad<real, NX, NU>, a.B, stream, a, ws);
+    ALQP_FOR_EACH_DIMS(X)
+#undef X
+    return ALQP_E_UNSUPPORTED;
+}
+
+template <typename real>
 int dispatch_step(int nx, int nu, const StepArgs<real> &a, hipStream_t stream) {
 #define X(NX, NU) \
     if (nx == NX && nu == NU) return launch_team_kernel<real, NX, NU>(k_newton_step<real, NX, NU>, a.B, a.T, stream, a);
@@ -659,6 +705,22 @@ int backward_impl(const AlqpDims *dims, const void *factor, const void *F, const
 }
 
 template <typename real>
+int backward_ws_impl(const AlqpDims *dims, void *workspace, size_t ws_bytes, const void *F, const void *rho,
+                     const void *z_final, const void *gbar, void *q_grad, void *Qd_grad, void *stream) {
+    if (!dims_ok(dims) || !workspace || !F || !rho || !z_final || !gbar || !q_grad || !Qd_grad)
+        return ALQP_E_BADARG;
+    const size_t need = quad_ws_bytes<real>(dims->nx, dims->nu, dims->B, dims->T);
+    if (need == 0) return ALQP_E_UNSUPPORTED;
+    if (ws_bytes < need) return ALQP_E_BADARG;
+    BwdArgs<real> a = {};
+    a.B = dims->B; a.T = dims->T;
+    a.F = (const real *)F; a.rho = (const real *)rho;
+    a.z_final = (const real *)z_final; a.gbar = (const real *)gbar;
+    a.q_grad = (real *)q_grad; a.Qd_grad = (real *)Qd_grad;
+    return dispatch_backward_quad<real>(dims->nx, dims->nu, a, (real *)workspace, (hipStream_t)stream);
+}
+
+template <typename real>
 int merit_impl(const AlqpDims *dims, int K, const void *zc, const void *xnext, const void *x0,
                const void *lam, const void *rho, const void *Qd, const void *q, const void *u_lo,
                const void *u_hi, long sb_u, long st_u, void *phi, void *rnorm2, void *stream) {
@@ -706,7 +768,7 @@ int dual_impl(const AlqpDims *dims, const void *z, const void *xnext, const void
 // ---- C ABI -------------------------------------------------------------------------------
 extern "C" {
 
-int alqp_abi_version(void) { return 2; }
+int alqp_abi_version(void) { return 3; }
 
 size_t alqp_workspace_bytes(const AlqpDims *dims, int is_f64) {
     if (!alqp::dims_ok(dims)) return 0;
@@ -778,5 +840,16 @@ int alqp_qps_per_wave(const AlqpDims *dims, int is_f64) {
 
 ALQP_DEFINE(f32, float)
 ALQP_DEFINE(f64, double)
+
+int alqp_backward_ws_f32(const AlqpDims *dims, void *workspace, size_t ws_bytes, const void *F,
+                         const void *rho, const void *z_final, const void *gbar, void *q_grad,
+                         void *Qd_grad, void *stream) {
+    return alqp::backward_ws_impl<float>(dims, workspace, ws_bytes, F, rho, z_final, gbar, q_grad, Qd_grad, stream);
+}
+int alqp_backward_ws_f64(const AlqpDims *dims, void *workspace, size_t ws_bytes, const void *F,
+                         const void *rho, const void *z_final, const void *gbar, void *q_grad,
+                         void *Qd_grad, void *stream) {
+    return alqp::backward_ws_impl<double>(dims, workspace, ws_bytes, F, rho, z_final, gbar, q_grad, Qd_grad, stream);
+}
 
 }  // extern "C"

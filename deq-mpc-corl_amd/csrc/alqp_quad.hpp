@@ -478,6 +478,69 @@ struct Quad {
             if ((j & 3) == q && active) recp(T - 1)[C::oS + j] = dxn[j];
     }
 
+    // ---- forward substitution only, with the factor of a previous solve still in the workspace:
+    //      y_t = L_t^{-1} ( rhs_t + rho F_{t-1} L_{t-1}^{-T} y_{t-1} [x rows] ), rhs_t = -gbar_t.
+    //      Used by the backward pass of the implicit layer (NewtonAL.backward, al_utils.py:578-615);
+    //      leaves y_t in the record's y slot, where backward() picks it up.
+    __device__ __forceinline__ void solve_forward(const real *gbar) {
+        real e[N];
+#pragma unroll
+        for (int j = 0; j < N; ++j) e[j] = 0;
+        for (int t = 0; t < T; ++t) {
+            real *rp = recp(t);
+            real H[HT];
+#pragma unroll
+            for (int s = 0; s < SH; ++s)
+#pragma unroll
+                for (int c = 0; c <= s; ++c) {
+                    const int ql = (C::lanes_of(s) == 4 || q < C::lanes_of(s)) ? q : 0;
+                    gld4(rp + C::oL + C::lbase(s) + c * 4 * C::lanes_of(s) + 4 * ql, H[C::hidx(s, 4 * c)],
+                         H[C::hidx(s, 4 * c + 1)], H[C::hidx(s, 4 * c + 2)], H[C::hidx(s, 4 * c + 3)]);
+                }
+            real Y[N];
+            gload<N>(gbar + t * N, Y);
+            real W[SW][N];
+            load_F_rows(t > 0 ? t - 1 : 0, W);
+#pragma unroll
+            for (int j = 0; j < N; ++j) Y[j] = -Y[j];
+            if (t > 0) {
+                real cpl[SW];
+#pragma unroll
+                for (int s = 0; s < SW; ++s) {
+                    real p = 0;
+#pragma unroll
+                    for (int k = 0; k < N; ++k) p = fma_(W[s][k], e[k], p);
+                    cpl[s] = p;
+                }
+#pragma unroll
+                for (int j = 0; j < NX; ++j) Y[j] = fma_(rho, qbv(cpl[j >> 2], j), Y[j]);
+            }
+            // y = L^{-1} rhs
+#pragma unroll
+            for (int j = 0; j < N; ++j) {
+                const real yj = Y[j] * qbv(H[C::hidx(j >> 2, j)], j);
+                Y[j] = yj;
+#pragma unroll
+                for (int k = j + 1; k < N; ++k) Y[k] = fma_(-qbv(H[C::hidx(k >> 2, j)], k), yj, Y[k]);
+            }
+            if (active) {
+#pragma unroll
+                for (int j = 0; j < N; ++j)
+                    if ((j & 3) == q) rp[C::oY + j] = Y[j];
+            }
+            // e = L^{-T} y for the coupling of the next stage
+#pragma unroll
+            for (int j = 0; j < N; ++j) e[j] = Y[j];
+#pragma unroll
+            for (int i = N - 1; i >= 0; --i) {
+                const real ei = e[i] * qbv(H[C::hidx(i >> 2, i)], i);
+                e[i] = ei;
+#pragma unroll
+                for (int j = 0; j < i; ++j) e[j] = fma_(-qbv(H[C::hidx(i >> 2, j)], i), ei, e[j]);
+            }
+        }
+    }
+
     // ---- merit of K candidates (see Team::merit_candidates for the algebra) ---------------
     // All loads of a stage are unconditional (clamped indices, masked contributions) so they
     // leave in one batch.

@@ -83,7 +83,8 @@ class _ALSolve(torch.autograd.Function):
         ctx.mpc = mpc
         ctx.has_factor = saved is not None
         if saved is not None:
-            factor, F_last, rho_last = saved
+            kind, factor, F_last, rho_last = saved
+            ctx.factor_kind = kind  # "packed" (team kernels) or "workspace" (quad solve's workspace)
             ctx.save_for_backward(factor, F_last, rho_last, st.z)
         ctx.dims = (st.z.shape[0], mpc.T, mpc.n_state, mpc.n_ctrl)
         return st.z.clone()
@@ -96,7 +97,10 @@ class _ALSolve(torch.autograd.Function):
         gbar = gz.to(z_final.dtype).contiguous()
         q_grad = torch.empty_like(z_final)
         Qd_grad = torch.empty_like(z_final)
-        ctx.mpc.backend.backward(ctx.dims, factor, F_last, rho_last, z_final, gbar, q_grad, Qd_grad)
+        if ctx.factor_kind == "workspace":
+            ctx.mpc.backend.backward_ws(ctx.dims, factor, F_last, rho_last, z_final, gbar, q_grad, Qd_grad)
+        else:
+            ctx.mpc.backend.backward(ctx.dims, factor, F_last, rho_last, z_final, gbar, q_grad, Qd_grad)
         return Qd_grad, q_grad, None
 
 
@@ -334,6 +338,10 @@ class MPC(Module):
         lo, hi, sb, stt = bnd
         common = dict(rnorm2=ws["rn2"], info=ws["info"], status=ws["status"], n_ls=N_LS,
                       rho_scale=RHO_SCALE)
+        if ws.get("qws") is not None:   # quad solve on a private workspace: it IS the saved factor
+            common["workspace"] = ws["qws"]
+            common["variant"] = "quad"
+            need_factor = False
         fl_save = _abi.ALQP_SAVE_FACTOR if need_factor else 0
         if self.exit_mode == "fixed":
             be.solve_lin(dims, Qd, q, F, c, st.x0, lo, hi, sb, stt, st.z, st.lam, st.rho, ws["phi"],
@@ -415,9 +423,13 @@ class MPC(Module):
         ws = {"phi": torch.zeros(B, dtype=dt, device=dev), "rn2": torch.zeros(B, dtype=dt, device=dev),
               "info": torch.zeros(B, dtype=torch.int32, device=dev),
               "status": torch.ones(B, dtype=torch.uint8, device=dev)}
-        if need_grad:
-            ws["factor"] = torch.empty(B, T, n * (n + 1) // 2, dtype=dt, device=dev)
         lin = st.lin
+        use_qws = need_grad and hasattr(be, "backward_ws") and (lin is not None or
+                                                                (bool(self.linearize_once) and st.stream_mode))
+        if use_qws:
+            ws["qws"] = be.new_workspace(dims, st.z)
+        elif need_grad:
+            ws["factor"] = torch.empty(B, T, n * (n + 1) // 2, dtype=dt, device=dev)
         stream = st.stream_mode
         linearize_once = bool(self.linearize_once) and stream
         npa = []
@@ -448,11 +460,13 @@ class MPC(Module):
 
         # ---- fast path: the whole solve in ONE launch -----------------------------------
         if F is not None and not stream and self.exit_mode == "fixed":
-            flags = _abi.ALQP_INIT_MERIT | _abi.ALQP_DUAL_UPDATE | (_abi.ALQP_SAVE_FACTOR if need_grad else 0)
+            save = need_grad and not use_qws
+            flags = _abi.ALQP_INIT_MERIT | _abi.ALQP_DUAL_UPDATE | (_abi.ALQP_SAVE_FACTOR if save else 0)
+            extra = dict(workspace=ws["qws"], variant="quad") if use_qws else {}
             be.solve_lin(dims, Qd, q, F, c, st.x0, lo, hi, sb, stt, st.z, st.lam, st.rho, ws["phi"],
                          rnorm2=ws["rn2"], info=ws["info"], status=ws["status"],
                          factor=ws.get("factor"), al_iter=self.al_iter, max_newton=MAX_NEWTON,
-                         n_ls=N_LS, flags=flags, rho_scale=RHO_SCALE)
+                         n_ls=N_LS, flags=flags, rho_scale=RHO_SCALE, **extra)
             npa = [MAX_NEWTON] * self.al_iter
             rho_last = st.rho / RHO_SCALE
             F_last = F
@@ -474,6 +488,8 @@ class MPC(Module):
                     F_last = ws.get("F_last")
                 # dual update with the TRUE dynamics (AL_mpc.py:315-317 / :397-399)
                 if F is not None and not linearize_once:
+                    # (never on the private workspace: its y/r/s slots may be rewritten, its L not,
+                    #  but keep the saved factor's workspace out of later launches altogether)
                     be.solve_lin(dims, Qd, q, F, c, st.x0, lo, hi, sb, stt, st.z, st.lam, st.rho,
                                  ws["phi"], rnorm2=ws["rn2"], info=None, status=ws["status"],
                                  al_iter=1, max_newton=0, n_ls=N_LS, flags=_abi.ALQP_DUAL_UPDATE,
@@ -498,5 +514,7 @@ class MPC(Module):
         self.last_info = ws["info"]
         self.dyn_res_prev = ws["rn2"].sqrt()
         if need_grad and F_last is not None:
-            return ws["factor"], F_last, rho_last
+            if use_qws:
+                return "workspace", ws["qws"], F_last, rho_last
+            return "packed", ws["factor"], F_last, rho_last
         return None

@@ -175,6 +175,18 @@ int alqp_backward_f64(const AlqpDims *dims, const void *factor, const void *F, c
                       const void *z_final, const void *gbar, void *q_grad, void *Qd_grad,
                       void *stream);
 
+/*
+ * Same backward pass, with the factor taken from the workspace a quad-variant
+ * alqp_solve_lin_* call left behind (the caller must have kept that workspace untouched:
+ * give such solves a dedicated workspace). The workspace's y/d slots are overwritten.
+ */
+int alqp_backward_ws_f32(const AlqpDims *dims, void *workspace, size_t ws_bytes, const void *F,
+                         const void *rho, const void *z_final, const void *gbar, void *q_grad,
+                         void *Qd_grad, void *stream);
+int alqp_backward_ws_f64(const AlqpDims *dims, void *workspace, size_t ws_bytes, const void *F,
+                         const void *rho, const void *z_final, const void *gbar, void *q_grad,
+                         void *Qd_grad, void *stream);
+
 /* Library/ABI version, bumped when a signature changes. */
 int alqp_abi_version(void);
 
