@@ -2,11 +2,22 @@
 //
 // Build: hipcc --offload-arch=gfx950 -O3 -shared -fPIC -I../../include alqp_kernels.hip -o libmi_alqp.so
 // No torch types anywhere: plain device pointers in, kernel launches on the caller's stream.
+// The file can be compiled as one translation unit (default) or, to build in parallel, as
+// three objects: -DALQP_PART=1 (team kernels, helper kernels, C ABI), -DALQP_PART=2 (quad
+// kernels fp32), -DALQP_PART=3 (quad kernels fp64). See build.sh.
 #include <hip/hip_runtime.h>
 
 #include "alqp_team.hpp"
 #include "alqp_quad.hpp"
 #include "mi_alqp.h"
+
+#ifndef ALQP_PART
+#define ALQP_PART 0
+#endif
+#define ALQP_BUILD_MAIN (ALQP_PART == 0 || ALQP_PART == 1)
+#define ALQP_BUILD_QUAD (ALQP_PART == 0 || ALQP_PART == 2 || ALQP_PART == 3)
+#define ALQP_QUAD_F32 (ALQP_PART == 0 || ALQP_PART == 2)
+#define ALQP_QUAD_F64 (ALQP_PART == 0 || ALQP_PART == 3)
 
 namespace alqp {
 
@@ -55,6 +66,7 @@ __device__ inline unsigned opaque_zero() {
     return z;
 }
 
+#if ALQP_BUILD_MAIN
 // ---- fused LinDx solve -------------------------------------------------------------
 template <typename real, int NX, int NU, bool TRACE>
 __global__ __launch_bounds__(64, 2) void k_solve_lin(SolveArgs<real> a, TraceArgs<real> tr) {
@@ -192,6 +204,9 @@ __global__ __launch_bounds__(64, 2) void k_solve_lin(SolveArgs<real> a, TraceArg
     }
 }
 
+#endif  // ALQP_BUILD_MAIN
+
+#if ALQP_BUILD_QUAD
 // ---- fused LinDx solve, quad variant (4 lanes per instance, HBM workspace) --------------
 template <typename real, int NX, int NU, bool TRACE>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_solve_lin_quad(SolveArgs<real> a, TraceArgs<real> tr, real *ws) {
@@ -322,6 +337,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     }
 }
 
+#endif  // ALQP_BUILD_QUAD
+
+#if ALQP_BUILD_MAIN
 // ---- one Newton direction (nonlinear-caller mode) ----------------------------------
 template <typename real, int NX, int NU>
 __global__ __launch_bounds__(64) void k_newton_step(StepArgs<real> a) {
@@ -517,6 +535,8 @@ __global__ __launch_bounds__(64) void k_dual(AuxArgs<real> a) {
     if (lane == 0) a.rho_io[b] = rho * a.rho_scale;
 }
 
+#endif  // ALQP_BUILD_MAIN
+
 // ---- dispatch -------------------------------------------------------------------------
 
 // (nx, nu) instances compiled into the library. Anything else is ALQP_E_UNSUPPORTED:
@@ -526,6 +546,7 @@ __global__ __launch_bounds__(64) void k_dual(AuxArgs<real> a) {
 
 constexpr size_t kMaxLds = 160 * 1024;
 
+#if ALQP_BUILD_MAIN
 template <typename real, int NX, int NU>
 size_t lds_bytes_for(int T) {
     using C = Cfg<real, NX, NU>;
@@ -560,6 +581,15 @@ int dispatch_solve(int nx, int nu, const SolveArgs<real> &a, const TraceArgs<rea
     return ALQP_E_UNSUPPORTED;
 }
 
+#endif  // ALQP_BUILD_MAIN
+
+template <typename real>
+int dispatch_solve_quad(int nx, int nu, const SolveArgs<real> &a, const TraceArgs<real> *tr, real *ws,
+                        hipStream_t stream);
+template <typename real>
+int dispatch_backward_quad(int nx, int nu, const BwdArgs<real> &a, real *ws, hipStream_t stream);
+
+#if ALQP_BUILD_QUAD
 template <typename real, int NX, int NU, typename Fn, typename... Args>
 int launch_quad_kernel(Fn fn, int B, hipStream_t stream, Args... args) {
     const unsigned grid = (unsigned)((B + 15) / 16);
@@ -581,15 +611,6 @@ int dispatch_solve_quad(int nx, int nu, const SolveArgs<real> &a, const TraceArg
 }
 
 template <typename real>
-size_t quad_ws_bytes(int nx, int nu, int B, int T) {
-#define X(NX, NU) \
-    if (nx == NX && nu == NU) return QCfg<real, NX, NU>::ws_words(B, T) * sizeof(real);
-    ALQP_FOR_EACH_DIMS(X)
-#undef X
-    return 0;
-}
-
-template <typename real>
 int dispatch_backward_quad(int nx, int nu, const BwdArgs<real> &a, real *ws, hipStream_t stream) {
 #define X(NX, NU) \
     if (nx == NX && nu == NU) return launch_quad_kernel<real, NX, NU>(k_backward_quad<real, NX, NU>, a.B, stream, a, ws);
@@ -598,6 +619,27 @@ int dispatch_backward_quad(int nx, int nu, const BwdArgs<real> &a, real *ws, hip
     return ALQP_E_UNSUPPORTED;
 }
 
+#if ALQP_QUAD_F32
+template int dispatch_solve_quad<float>(int, int, const SolveArgs<float> &, const TraceArgs<float> *, float *, hipStream_t);
+template int dispatch_backward_quad<float>(int, int, const BwdArgs<float> &, float *, hipStream_t);
+#endif
+#if ALQP_QUAD_F64
+template int dispatch_solve_quad<double>(int, int, const SolveArgs<double> &, const TraceArgs<double> *, double *, hipStream_t);
+template int dispatch_backward_quad<double>(int, int, const BwdArgs<double> &, double *, hipStream_t);
+#endif
+
+#endif  // ALQP_BUILD_QUAD
+
+template <typename real>
+size_t quad_ws_bytes(int nx, int nu, int B, int T) {
+#define X(NX, NU) \
+    if (nx == NX && nu == NU) return QCfg<real, NX, NU>::ws_words(B, T) * sizeof(real);
+    ALQP_FOR_EACH_DIMS(X)
+#undef X
+    return 0;
+}
+
+#if ALQP_BUILD_MAIN
 template <typename real>
 int dispatch_step(int nx, int nu, const StepArgs<real> &a, hipStream_t stream) {
 #define X(NX, NU) \
@@ -763,9 +805,12 @@ int dual_impl(const AlqpDims *dims, const void *z, const void *xnext, const void
     return hipGetLastError() == hipSuccess ? 0 : ALQP_E_LAUNCH;
 }
 
+#endif  // ALQP_BUILD_MAIN
+
 }  // namespace alqp
 
 // ---- C ABI -------------------------------------------------------------------------------
+#if ALQP_BUILD_MAIN
 extern "C" {
 
 int alqp_abi_version(void) { return 3; }
@@ -853,3 +898,4 @@ int alqp_backward_ws_f64(const AlqpDims *dims, void *workspace, size_t ws_bytes,
 }
 
 }  // extern "C"
+#endif  // ALQP_BUILD_MAIN

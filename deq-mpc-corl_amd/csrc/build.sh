@@ -1,9 +1,16 @@
 #!/bin/bash
 # Builds libmi_alqp.so for gfx950 (MI355X). hipcc cross-compiles without a GPU.
+# alqp_kernels.hip is compiled as three objects in parallel (team+ABI, quad fp32, quad fp64).
 set -euo pipefail
 cd "$(dirname "$0")"
 # -pragma-unroll-threshold: the panel loops of alqp_quad.hpp must be fully unrolled (register
 # arrays need static indices); the default threshold silently leaves them rolled.
-hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC -I../../include \
-      -mllvm -pragma-unroll-threshold=1000000 \
-      alqp_kernels.hip -o libmi_alqp.so "$@"
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -I../../include -mllvm -pragma-unroll-threshold=1000000"
+mkdir -p build
+pids=()
+for part in 1 2 3; do
+  hipcc $FLAGS -DALQP_PART=$part -c alqp_kernels.hip -o build/alqp_part$part.o "$@" &
+  pids+=($!)
+done
+for p in "${pids[@]}"; do wait "$p"; done
+hipcc --offload-arch=gfx950 -shared -fPIC build/alqp_part1.o build/alqp_part2.o build/alqp_part3.o -o libmi_alqp.so
