@@ -208,6 +208,12 @@ __global__ __launch_bounds__(64, 2) void k_solve_lin(SolveArgs<real> a, TraceArg
 
 #if ALQP_BUILD_QUAD
 // ---- fused LinDx solve, quad variant (4 lanes per instance, HBM workspace) --------------
+#ifdef ALQP_PHASE_TIMING
+__device__ unsigned long long g_phase_cycles[10];
+#define QSTAMP(b) qd.stamp(b)
+#else
+#define QSTAMP(b)
+#endif
 template <typename real, int NX, int NU, bool TRACE>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_solve_lin_quad(SolveArgs<real> a, TraceArgs<real> tr, real *ws) {
     using C = QCfg<real, NX, NU>;
@@ -220,6 +226,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
 
     Quad<real, NX, NU> qd;
     qd.q = lane & 3;
+    // LDS image of the next stage's inputs (global->LDS DMA), one per wave
+    __shared__ __attribute__((aligned(16))) float stage_img[C::DMA ? C::IMGW : 4];
+    qd.init_image(stage_img, lane, blockIdx.x * 16, a.B, a.F, ws);
     qd.T = T;
     qd.active = active;
     qd.gQd = a.Qd + (size_t)b * T * N;
@@ -236,6 +245,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     qd.rho = a.rho[b];
     qd.info = 0;
     real phi_prev = a.phi[b];
+#ifdef ALQP_PHASE_TIMING
+    for (int i = 0; i < 10; ++i) qd.tacc[i] = 0;
+#endif
+    QSTAMP(-1);
     qd.residual_pass();
 
     int step_id = 0;
@@ -248,8 +261,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
         for (int st = 0; st < a.max_newton; ++st, ++step_id) {
             real *tg = nullptr;
             if constexpr (TRACE) tg = (tr.g && active) ? tr.g + ((size_t)step_id * a.B + b) * T * N : nullptr;
+            QSTAMP(9);  // everything between Newton steps
             qd.forward(tg);
             qd.backward();
+            QSTAMP(-1);
             if constexpr (TRACE) {
                 if (tr.d && active) {
                     real *td = tr.d + ((size_t)step_id * a.B + b) * T * N;
@@ -259,6 +274,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
             }
             real ph[20];
             qd.template merit_candidates<20>(ph, false);
+            QSTAMP(6);  // line-search candidates
             int kbest = 0;
             real best = ph[0];
 #pragma unroll
@@ -282,6 +298,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
             }
             const real alpha = acc ? real(1) / real(1 << kbest) : real(0);
             qd.apply_step(alpha);
+            QSTAMP(7);  // pick + apply
             phi_prev = best;  // merit <- new_merit even when rejected (al_utils.py:569)
         }
         if (a.flags & ALQP_DUAL_UPDATE) {
@@ -291,6 +308,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     }
     int bad = 0;
     const real rn2 = qd.rplus2(bad);
+#ifdef ALQP_PHASE_TIMING
+    QSTAMP(9);
+    if (lane == 0)
+        for (int i = 0; i < 10; ++i) atomicAdd(&g_phase_cycles[i], qd.tacc[i]);
+#endif
     if (active && qd.q == 0) {
         a.rho[b] = qd.rho;
         a.phi[b] = phi_prev;
@@ -313,6 +335,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     const int T = a.T;
     Quad<real, NX, NU> qd;
     qd.q = lane & 3;
+    // LDS image of the next stage's inputs (global->LDS DMA), one per wave
+    __shared__ __attribute__((aligned(16))) float stage_img[C::DMA ? C::IMGW : 4];
+    qd.init_image(stage_img, lane, blockIdx.x * 16, a.B, a.F, ws);
     qd.T = T;
     qd.active = active;
     qd.gF = a.F + (size_t)b * (T - 1) * NX * N;
@@ -899,3 +924,15 @@ int alqp_backward_ws_f64(const AlqpDims *dims, void *workspace, size_t ws_bytes,
 
 }  // extern "C"
 #endif  // ALQP_BUILD_MAIN
+
+#if defined(ALQP_PHASE_TIMING) && ALQP_QUAD_F32
+// debug build only: read (and optionally reset) the per-phase cycle counters of k_solve_lin_quad
+extern "C" int alqp_debug_phase_cycles(unsigned long long *out10, int reset) {
+    if (out10 && hipMemcpyFromSymbol(out10, HIP_SYMBOL(alqp::g_phase_cycles), 10 * sizeof(unsigned long long)) != hipSuccess) return -1;
+    if (reset) {
+        unsigned long long z[10] = {0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(alqp::g_phase_cycles), z, sizeof(z)) != hipSuccess) return -1;
+    }
+    return 0;
+}
+#endif
