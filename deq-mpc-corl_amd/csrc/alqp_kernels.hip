@@ -221,14 +221,17 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     const int lane = threadIdx.x, qi = lane >> 2;
     const int b_raw = blockIdx.x * 16 + qi;
     const bool active = b_raw < a.B;
+#ifdef ALQP_ALIAS_ALL
+    // experiment only (tools/phase_timing.sh -DALQP_ALIAS_ALL): every instance of an XCD-sized group
+    // works on the same data, so the launch runs out of L2: what remains is the on-chip time
+    const int b = (active ? b_raw : a.B - 1) % ALQP_ALIAS_ALL;
+#else
     const int b = active ? b_raw : a.B - 1;
+#endif
     const int T = a.T, M = C::M(T);
 
     Quad<real, NX, NU> qd;
     qd.q = lane & 3;
-    // LDS image of the next stage's inputs (global->LDS DMA), one per wave
-    __shared__ __attribute__((aligned(16))) float stage_img[C::DMA ? C::IMGW : 4];
-    qd.init_image(stage_img, lane, blockIdx.x * 16, a.B, a.F, ws);
     qd.T = T;
     qd.active = active;
     qd.gQd = a.Qd + (size_t)b * T * N;
@@ -249,9 +252,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     for (int i = 0; i < 10; ++i) qd.tacc[i] = 0;
 #endif
     QSTAMP(-1);
-    qd.residual_pass();
+    qd.stage_in((a.flags & ALQP_INIT_MERIT) || a.max_newton == 0 || a.al_iter == 0);
 
     int step_id = 0;
+    bool pend = false;  // a chosen step not yet applied (the next forward sweep applies it)
+    real alpha_pend = 0;
     for (int it = 0; it < a.al_iter; ++it) {
         if (a.flags & ALQP_INIT_MERIT) {
             real p1[1];
@@ -262,7 +267,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
             real *tg = nullptr;
             if constexpr (TRACE) tg = (tr.g && active) ? tr.g + ((size_t)step_id * a.B + b) * T * N : nullptr;
             QSTAMP(9);  // everything between Newton steps
-            qd.forward(tg);
+            qd.forward(tg, alpha_pend, pend);
             qd.backward();
             QSTAMP(-1);
             if constexpr (TRACE) {
@@ -297,7 +302,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
                 }
             }
             const real alpha = acc ? real(1) / real(1 << kbest) : real(0);
-            qd.apply_step(alpha);
+            pend = st + 1 < a.max_newton;
+            alpha_pend = alpha;
+            if (!pend) qd.apply_step(alpha);
             QSTAMP(7);  // pick + apply
             phi_prev = best;  // merit <- new_merit even when rejected (al_utils.py:569)
         }
@@ -308,6 +315,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     }
     int bad = 0;
     const real rn2 = qd.rplus2(bad);
+    qd.stage_out();
 #ifdef ALQP_PHASE_TIMING
     QSTAMP(9);
     if (lane == 0)
@@ -335,9 +343,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     const int T = a.T;
     Quad<real, NX, NU> qd;
     qd.q = lane & 3;
-    // LDS image of the next stage's inputs (global->LDS DMA), one per wave
-    __shared__ __attribute__((aligned(16))) float stage_img[C::DMA ? C::IMGW : 4];
-    qd.init_image(stage_img, lane, blockIdx.x * 16, a.B, a.F, ws);
     qd.T = T;
     qd.active = active;
     qd.gF = a.F + (size_t)b * (T - 1) * NX * N;

@@ -111,59 +111,6 @@ __device__ inline void gload(const real *p, real (&dst)[LEN]) {
     for (int c = (LEN / 4) * 4; c < LEN; ++c) dst[c] = p[c];
 }
 
-// ---- global -> LDS DMA (gfx950 global_load_lds_dword / _dwordx4) ----------------------
-// One wave-instruction moves SZ bytes per enabled lane from the lane's global address to LDS byte
-// M0 + IMM + SZ*lane, with no register destination (tools/probes/glds_probe.hip and
-// glds_x4_probe.hip pin the semantics used here: per-lane source that only needs 4-byte
-// alignment, lane-linear destination, the immediate offset applied to BOTH addresses, the
-// SGPR-base + VGPR-offset form, lanes switched off by EXEC write nothing). M0 is
-// compiler-reserved: it is saved, written and restored inside the one statement. hipcc does not
-// count an asm load in its s_waitcnt bookkeeping: the sweeps wait with dma_wait<>().
-// What a DMA instruction costs is its pass through the CU's address unit (about one clock per
-// 128-byte line touched, shared by the CU's four waves), so the images below are laid out for
-// few, wide instructions.
-template <int M0ADD, int IMM>
-__device__ __forceinline__ void glds_dword(const void *gsrc, unsigned lds_base) {
-    static_assert(IMM >= 0 && IMM < 4096 && M0ADD >= 0, "13-bit signed immediate");
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_add_u32 m0, %2, %3\n\ts_nop 0\n\tglobal_load_lds_dword %1, off offset:%4\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep)
-                 : "v"(gsrc), "s"(lds_base), "i"(M0ADD), "i"(IMM)
-                 : "memory", "scc");
-}
-template <int M0ADD, int IMM>
-__device__ __forceinline__ void glds_x4(const void *gsrc, unsigned lds_base) {
-    static_assert(IMM >= 0 && IMM < 4096 && M0ADD >= 0, "13-bit signed immediate");
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_add_u32 m0, %2, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off offset:%4\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep)
-                 : "v"(gsrc), "s"(lds_base), "i"(M0ADD), "i"(IMM)
-                 : "memory", "scc");
-}
-// wave-uniform base (SGPR pair) + per-lane byte offset
-template <int M0ADD>
-__device__ __forceinline__ void glds_x4_u(const void *sbase, unsigned voff, unsigned lds_base) {
-    static_assert(M0ADD >= 0, "");
-    unsigned keep;
-    // the base IS uniform; readfirstlane makes the register class certain ("s" alone is not)
-    const unsigned long long a = (unsigned long long)(uintptr_t)sbase;
-    const unsigned long long su = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(a >> 32)) << 32) |
-                                  (unsigned)__builtin_amdgcn_readfirstlane((int)(a & 0xffffffffull));
-    asm volatile("s_mov_b32 %0, m0\n\ts_add_u32 m0, %3, %4\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep)
-                 : "v"(voff), "s"(su), "s"(lds_base), "i"(M0ADD)
-                 : "memory", "scc");
-}
-// vmcnt counts loads, stores and DMA together, in issue order: "all but the KEEP youngest are
-// done". KEEP must be a LOWER bound of the vector-memory instructions issued after the DMA being
-// waited for (the stage's result stores), or the image is read before it has landed.
-template <int KEEP = 0>
-__device__ __forceinline__ void dma_wait() {
-    static_assert(KEEP >= 0 && KEEP < 64, "6-bit vmcnt");
-    asm volatile("s_waitcnt vmcnt(%0)" ::"i"(KEEP) : "memory");
-}
-__device__ __forceinline__ void lds_reads_done() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
-
 template <typename real, int NX_, int NU_>
 struct QCfg {
     static constexpr int NX = NX_, NU = NU_, N = NX_ + NU_;
@@ -184,48 +131,24 @@ struct QCfg {
         return o;
     }
     static constexpr int LW = lbase(SH);
+    __host__ __device__ static constexpr int p4(int x) { return (x + 3) & ~3; }
+    // The record also carries the stage's slice of every small per-stage array (working copies
+    // of z and lam, copies of diag Q, q, c and the bounds): in their own arrays these are 52-68
+    // byte pieces, each costing one or two 128-byte lines per touch; side by side in the record
+    // the sweeps and the line search touch a few whole lines. stage_in()/stage_out() copy them.
     static constexpr int oL = 0;
-    static constexpr int oY = oL + ((LW + 3) & ~3);  // y_t, later d_t : element k at oY + k
+    static constexpr int oY = oL + p4(LW);         // y_t, later d_t : element k at oY + k
     static constexpr int oR = oY + 4 * SY;         // r_t (eq residual of row block t): row r at oR + r
     static constexpr int oS = oR + 4 * SW;         // s_t = (J d)_eq
-    static constexpr int RECW = oS + 4 * SW;
-    // LDS stage image: the inputs of the NEXT stage are fetched by DMA while the current stage
-    // computes (one wave per SIMD: nothing else hides the HBM latency). Two layouts:
-    //  big segments (F_t, the workspace record): instance-major, one x4 instruction per instance
-    //    (up to 1 KB contiguous), instance p at word p*stride, stride = 4 mod 32 (bank spread);
-    //  small segments: chunk-interleaved over the 16 instances, one x4 instruction per 16 words
-    //    of every instance (word e of instance p at 256*(e/16) + 16p + e%16).
-    // The LEN%4 trailing words of a segment travel in one dword instruction into a 64-word block
-    // (word r of instance p at 4p + r): a DMA never reads past the end of a segment.
-    __host__ __device__ static constexpr int big_stride(int len) {
-        int st = len;
-        while ((st & 31) != 4) ++st;
-        return st;
-    }
-    __host__ __device__ static constexpr int small_words(int len) {  // image words of a small segment
-        return ((len / 4 + 3) / 4) * 256 + ((len % 4) ? 64 : 0);
-    }
-    static constexpr int SF = big_stride(NX * N), SR = big_stride(oY + N);
-    static constexpr int iF = 0;                          // F_t rows (both sweeps)
-    static constexpr int iFt = iF + 16 * SF;              // ... trailing words
-    static constexpr int fZ = iFt + 64;                   // forward: z_t
-    static constexpr int fZN = fZ + small_words(N);       //          z_{t+1}[x]
-    static constexpr int fQ = fZN + small_words(NX);      //          diag Q_t
-    static constexpr int fq = fQ + small_words(N);        //          q_t
-    static constexpr int fC = fq + small_words(N);        //          c_t
-    static constexpr int fLE = fC + small_words(NX);      //          lam (dynamics rows t)
-    static constexpr int fLU = fLE + small_words(NX);     //          lam (upper | lower bound rows t)
-    static constexpr int fBU = fLU + small_words(2 * NU); //          u_upper
-    static constexpr int fBL = fBU + small_words(NU);     //          u_lower
-    static constexpr int FWDW = fBL + small_words(NU);
-    static constexpr int bR = iFt + 64;                   // backward: workspace record words [0, oY + N)
-    static constexpr int bRt = bR + 16 * SR;
-    static constexpr int BWDW = bRt + 64;
-    static constexpr int IMGW = FWDW > BWDW ? FWDW : BWDW;  // whole-wave image, in words
-    static constexpr int LDS_BYTES = IMGW * 4;
-    // 4 waves per CU share 160 KB of LDS; fp64 keeps the register-load path
-    static constexpr bool DMA = sizeof(real) == 4 && LDS_BYTES <= 38 * 1024 && NX * N <= 256 && oY + N <= 256 &&
-                                15 * SF + 4 * SW * N <= IMGW;
+    static constexpr int oZ = oS + 4 * SW;         // z_t
+    static constexpr int oLE = oZ + 4 * SY;        // lam, equality row block t
+    static constexpr int oLU = oLE + 4 * SW;       // lam, bound rows of stage t: [upper NU | lower NU]
+    static constexpr int oBU = oLU + p4(2 * NU);   // u_upper(t)
+    static constexpr int oBL = oBU + p4(NU);       // u_lower(t)
+    static constexpr int oQ = oBL + p4(NU);        // diag Q_t
+    static constexpr int oq = oQ + 4 * SY;         // q_t
+    static constexpr int oC = oq + 4 * SY;         // c_t
+    static constexpr int RECW = (oC + 4 * SW + 31) & ~31;  // whole 128-byte lines (fp32)
     __host__ __device__ static constexpr int M(int T) { return T * NX + 2 * T * NU; }
     __host__ __device__ static constexpr size_t ws_words(int B, int T) { return (size_t)B * T * RECW; }
 };
@@ -242,203 +165,18 @@ struct Quad {
     real *gz, *glam, *rec;
     real rho;
     int info;
-    // DMA path (C::DMA): the wave's stage image in LDS
-    float *lds;
-    unsigned ldsb;       // its LDS byte address (M0 base)
-    int lane, ip;        // lane in the wave, instance within the wave (lane / 4)
-    int b0, Bn;          // first instance of the wave, batch size (wave-uniform)
-    const real *uF;      // wave-uniform bases of the big segments
-    const real *urec;
-
-    __device__ __forceinline__ void init_image(float *img, int lane_, int b0_, int Bn_, const real *F_, const real *ws_) {
-        lds = img;
-        ldsb = (unsigned)(uintptr_t)img;
-        lane = lane_;
-        ip = lane_ >> 2;
-        b0 = b0_;
-        Bn = Bn_;
-        uF = F_;
-        urec = ws_;
-    }
-    // ---- small segments
-    template <int LEN, int OFF>
-    __device__ __forceinline__ void dma_small(const real *seg) const {
-        constexpr int NCH = LEN / 4, R = LEN % 4, NB = (NCH + 3) / 4;
-        const float *src = (const float *)seg + 4 * q;
-        if constexpr (NB >= 1) { if (q < NCH) glds_x4<OFF * 4, 0>(src, ldsb); }
-        if constexpr (NB >= 2) { if (4 + q < NCH) glds_x4<(OFF + 256) * 4 - 64, 64>(src, ldsb); }
-        if constexpr (NB >= 3) { if (8 + q < NCH) glds_x4<(OFF + 512) * 4 - 128, 128>(src, ldsb); }
-        static_assert(NB <= 3, "small segment longer than 48 words");
-        if constexpr (R > 0) { if (q < R) glds_dword<(OFF + 256 * NB) * 4, 0>((const float *)seg + 4 * NCH + q, ldsb); }
-    }
-    template <int LEN, int OFF>
-    __device__ __forceinline__ float small_rep(int e) const {  // word e, the same in the 4 lanes
-        constexpr int NCH = LEN / 4, NB = (NCH + 3) / 4;
-        if (e < 4 * NCH) return lds[OFF + 256 * (e >> 4) + (e & 15) + 16 * ip];
-        return lds[OFF + 256 * NB + (e - 4 * NCH) + 4 * ip];
-    }
-    template <int LEN, int OFF>
-    __device__ __forceinline__ float small_own(int m) const {  // word 4m+q (garbage past LEN)
-        constexpr int NCH = LEN / 4, NB = (NCH + 3) / 4;
-        if (m < NCH) return lds[OFF + 256 * ((4 * m) >> 4) + ((4 * m) & 15) + q + 16 * ip];
-        return lds[OFF + 256 * NB + q + 4 * ip];
-    }
-    // ---- big segments: instance P of the wave from ubase + min(b0 + P, Bn - 1) * stride
-    template <int LEN, int ST_, int OFF, int P>
-    __device__ __forceinline__ void big_unit(const real *ubase, size_t stride) const {
-        constexpr int NCH = LEN / 4;
-        static_assert(NCH <= 64, "one instruction per instance");
-        const int bp = (b0 + P < Bn) ? b0 + P : Bn - 1;
-        if (lane < NCH) glds_x4_u<(OFF + P * ST_) * 4>(ubase + (size_t)bp * stride, 16u * lane, ldsb);
-    }
-    template <int LEN, int OFFT>
-    __device__ __forceinline__ void big_tail(const real *own_seg) const {
-        constexpr int NCH = LEN / 4, R = LEN % 4;
-        if constexpr (R > 0) { if (q < R) glds_dword<OFFT * 4, 0>((const float *)own_seg + 4 * NCH + q, ldsb); }
-    }
-    // F[4s+q][k] of the image (zeros for rows >= NX)
-    __device__ __forceinline__ void read_F_image(real (&W)[SW][N]) const {
-        constexpr int NCH = (NX * N) / 4, R = (NX * N) % 4;
-        constexpr int SL = (NX - 1) / 4, QL = (NX - 1) % 4;  // slot / lane of the last row
-        const float *rowp = lds + C::iF + ip * C::SF + q * N;
-#pragma unroll
-        for (int s = 0; s < SW; ++s)
-#pragma unroll
-            for (int k = 0; k < N; ++k) {
-                real v = rowp[4 * s * N + k];
-                if (R > 0 && s == SL && k >= N - R) {  // trailing words of the segment: last row only
-                    const real tv = lds[C::iFt + 4 * ip + (k - (N - R))];
-                    v = (q == QL) ? tv : v;
-                }
-                W[s][k] = (4 * s + 3 < NX || 4 * s + q < NX) ? v : real(0);
-            }
-        static_assert(NCH * 4 + R == NX * N && NX <= 16 && 2 * N <= 40, "slot switches");
-    }
-    // The DMA of a stage is a list of units (one or two instructions each). A wave that issues
-    // them back to back sits in the CU's memory pipeline for thousands of cycles (measured: 20 %
-    // of the kernel), so inside the sweeps they are issued a few at a time between the blocks of
-    // arithmetic of the stage before.
-    static constexpr int FWD_UNITS = 26, BWD_UNITS = 34;
-    template <int U>
-    __device__ __forceinline__ void fwd_unit(int t, int td) const {
-        if constexpr (U < 16) big_unit<NX * N, C::SF, C::iF, U>(uF + (size_t)td * NX * N, (size_t)(T - 1) * NX * N);
-        else if constexpr (U == 16) big_tail<NX * N, C::iFt>(gF + (size_t)td * NX * N);
-        else if constexpr (U == 17) dma_small<N, C::fZ>(gz + t * N);
-        else if constexpr (U == 18) dma_small<NX, C::fZN>(gz + (td + 1) * N);
-        else if constexpr (U == 19) dma_small<N, C::fQ>(gQd + t * N);
-        else if constexpr (U == 20) dma_small<N, C::fq>(gq + t * N);
-        else if constexpr (U == 21) dma_small<NX, C::fC>(gc + td * NX);
-        else if constexpr (U == 22) dma_small<NX, C::fLE>(glam + td * NX);
-        else if constexpr (U == 23) dma_small<2 * NU, C::fLU>(glam + T * NX + t * 2 * NU);
-        else if constexpr (U == 24) dma_small<NU, C::fBU>(guhi + t * st_u);
-        else if constexpr (U == 25) dma_small<NU, C::fBL>(gulo + t * st_u);
-    }
-    template <int U0, int CNT>
-    __device__ __forceinline__ void fwd_units(int t) const {
-        if constexpr (CNT > 0 && U0 < FWD_UNITS) {
-            fwd_unit<U0>(t, (t < T - 1) ? t : (T > 1 ? T - 2 : 0));  // valid addresses for the last stage
-            fwd_units<U0 + 1, CNT - 1>(t);
-        }
-    }
-    template <int U>
-    __device__ __forceinline__ void bwd_unit(int t, int td) const {
-        if constexpr (U < 16) big_unit<NX * N, C::SF, C::iF, U>(uF + (size_t)td * NX * N, (size_t)(T - 1) * NX * N);
-        else if constexpr (U == 16) big_tail<NX * N, C::iFt>(gF + (size_t)td * NX * N);
-        else if constexpr (U < 33) big_unit<C::oY + N, C::SR, C::bR, U - 17>(urec + (size_t)t * RECW, (size_t)T * RECW);
-        else if constexpr (U == 33) big_tail<C::oY + N, C::bRt>(recp(t));
-    }
-    template <int U0, int CNT>
-    __device__ __forceinline__ void bwd_units(int t) const {
-        if constexpr (CNT > 0 && U0 < BWD_UNITS) {
-            bwd_unit<U0>(t, (t < T - 1) ? t : (T > 1 ? T - 2 : 0));
-            bwd_units<U0 + 1, CNT - 1>(t);
-        }
-    }
-    // slot is a constant after unrolling: the switch folds away (a loop variable cannot be a
-    // template argument)
-    template <int UPS>
-    __device__ __forceinline__ void fwd_slot(int slot, int t) const {
-        switch (slot) {
-            case 0: fwd_units<0 * UPS, UPS>(t); break;
-            case 1: fwd_units<1 * UPS, UPS>(t); break;
-            case 2: fwd_units<2 * UPS, UPS>(t); break;
-            case 3: fwd_units<3 * UPS, UPS>(t); break;
-            case 4: fwd_units<4 * UPS, UPS>(t); break;
-            case 5: fwd_units<5 * UPS, UPS>(t); break;
-            case 6: fwd_units<6 * UPS, UPS>(t); break;
-            case 7: fwd_units<7 * UPS, UPS>(t); break;
-            case 8: fwd_units<8 * UPS, UPS>(t); break;
-            case 9: fwd_units<9 * UPS, UPS>(t); break;
-            case 10: fwd_units<10 * UPS, UPS>(t); break;
-            case 11: fwd_units<11 * UPS, UPS>(t); break;
-            case 12: fwd_units<12 * UPS, UPS>(t); break;
-            case 13: fwd_units<13 * UPS, UPS>(t); break;
-            case 14: fwd_units<14 * UPS, UPS>(t); break;
-            case 15: fwd_units<15 * UPS, UPS>(t); break;
-            default: break;
-        }
-    }
-    template <int UPS>
-    __device__ __forceinline__ void bwd_slot(int slot, int t) const {
-        switch (slot) {
-            case 0: bwd_units<0 * UPS, UPS>(t); break;
-            case 1: bwd_units<1 * UPS, UPS>(t); break;
-            case 2: bwd_units<2 * UPS, UPS>(t); break;
-            case 3: bwd_units<3 * UPS, UPS>(t); break;
-            case 4: bwd_units<4 * UPS, UPS>(t); break;
-            case 5: bwd_units<5 * UPS, UPS>(t); break;
-            case 6: bwd_units<6 * UPS, UPS>(t); break;
-            case 7: bwd_units<7 * UPS, UPS>(t); break;
-            case 8: bwd_units<8 * UPS, UPS>(t); break;
-            case 9: bwd_units<9 * UPS, UPS>(t); break;
-            case 10: bwd_units<10 * UPS, UPS>(t); break;
-            case 11: bwd_units<11 * UPS, UPS>(t); break;
-            case 12: bwd_units<12 * UPS, UPS>(t); break;
-            case 13: bwd_units<13 * UPS, UPS>(t); break;
-            case 14: bwd_units<14 * UPS, UPS>(t); break;
-            case 15: bwd_units<15 * UPS, UPS>(t); break;
-            case 16: bwd_units<16 * UPS, UPS>(t); break;
-            case 17: bwd_units<17 * UPS, UPS>(t); break;
-            case 18: bwd_units<18 * UPS, UPS>(t); break;
-            case 19: bwd_units<19 * UPS, UPS>(t); break;
-            case 20: bwd_units<20 * UPS, UPS>(t); break;
-            case 21: bwd_units<21 * UPS, UPS>(t); break;
-            case 22: bwd_units<22 * UPS, UPS>(t); break;
-            case 23: bwd_units<23 * UPS, UPS>(t); break;
-            case 24: bwd_units<24 * UPS, UPS>(t); break;
-            case 25: bwd_units<25 * UPS, UPS>(t); break;
-            case 26: bwd_units<26 * UPS, UPS>(t); break;
-            case 27: bwd_units<27 * UPS, UPS>(t); break;
-            case 28: bwd_units<28 * UPS, UPS>(t); break;
-            case 29: bwd_units<29 * UPS, UPS>(t); break;
-            case 30: bwd_units<30 * UPS, UPS>(t); break;
-            case 31: bwd_units<31 * UPS, UPS>(t); break;
-            case 32: bwd_units<32 * UPS, UPS>(t); break;
-            case 33: bwd_units<33 * UPS, UPS>(t); break;
-            case 34: bwd_units<34 * UPS, UPS>(t); break;
-            case 35: bwd_units<35 * UPS, UPS>(t); break;
-            case 36: bwd_units<36 * UPS, UPS>(t); break;
-            case 37: bwd_units<37 * UPS, UPS>(t); break;
-            case 38: bwd_units<38 * UPS, UPS>(t); break;
-            case 39: bwd_units<39 * UPS, UPS>(t); break;
-            default: break;
-        }
-    }
-    __device__ __forceinline__ void issue_forward_dma(int t) const { fwd_units<0, FWD_UNITS>(t); }
-    __device__ __forceinline__ void issue_backward_dma(int t) const { bwd_units<0, BWD_UNITS>(t); }
 
     __device__ __forceinline__ real uhi(int t, int j) const { return guhi[t * st_u + j]; }
     __device__ __forceinline__ real ulo(int t, int j) const { return gulo[t * st_u + j]; }
     __device__ __forceinline__ real *recp(int t) const { return rec + (size_t)t * RECW; }
 #ifdef ALQP_PHASE_TIMING
-    // debug build only (tools/phase_timing.py): cycles per phase. A stamp does not drain the
-    // vector-memory queue (the DMA of the next stage has to stay in flight): waits show up in the
-    // bucket of the statement that blocks on them
+    // debug build only (tools/phase_timing.py): cycles per phase; a stamp drains the memory queue,
+    // so "wait" buckets hold the exposed latency of the loads issued before them
     unsigned long long tacc[10], tlast;
     __device__ __forceinline__ void stamp(int bucket) {
         unsigned long long now;
         __builtin_amdgcn_sched_barrier(0);
-        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(now)::"memory");
+        asm volatile("s_waitcnt vmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(now)::"memory");
         __builtin_amdgcn_sched_barrier(0);
         if (bucket >= 0) tacc[bucket] += now - tlast;
         tlast = now;
@@ -465,45 +203,94 @@ struct Quad {
             }
         }
     }
-    // equality residuals of all stages at the current z -> workspace (kernel start)
-    __device__ __forceinline__ void residual_pass() {
-        for (int t = 0; t < T - 1; ++t) {
-            real W[SW][N], zt[N];
-            load_F_rows(t, W);
-            gload<N>(gz + t * N, zt);
+    // LEN contiguous words src -> dst, the quad's lanes taking 16-byte chunks in turn
+    template <int LEN>
+    __device__ __forceinline__ void copy_slice(const real *src, real *dst) const {
 #pragma unroll
-            for (int s = 0; s < SW; ++s) {
-                const int r = 4 * s + q;
-                if (r < NX) {
-                    real xn = gc[t * NX + r];
+        for (int c = 0; 16 * c < LEN; ++c) {
+            const int w0 = 16 * c + 4 * q;
+            if (16 * c + 15 < LEN || w0 + 3 < LEN) {
+                real a, b, cc, d;
+                gld4(src + w0, a, b, cc, d);
+                gst4(dst + w0, a, b, cc, d);
+            } else {
 #pragma unroll
-                    for (int k = 0; k < N; ++k) xn = fma_(W[s][k], zt[k], xn);
-                    if (active) recp(t)[C::oR + r] = gz[(t + 1) * N + r] - xn;
+                for (int w = 0; w < 4; ++w)
+                    if (w0 + w < LEN) dst[w0 + w] = src[w0 + w];
+            }
+        }
+    }
+    // Kernel start: the stage's slice of z, lam, diag Q, q, c and the bounds -> its record, and
+    // (when the launch starts with a merit evaluation or is a dual update only) the equality
+    // residuals at the current z; a forward sweep recomputes them anyway.
+    __device__ __forceinline__ void stage_in(bool with_residual) {
+#pragma unroll 2
+        for (int t = 0; t < T; ++t) {
+            const bool dyn = t < T - 1;
+            real *rp = recp(t);
+            if (active) {
+                copy_slice<N>(gz + t * N, rp + C::oZ);
+                copy_slice<N>(gQd + t * N, rp + C::oQ);
+                copy_slice<N>(gq + t * N, rp + C::oq);
+                copy_slice<NX>(glam + t * NX, rp + C::oLE);
+                copy_slice<2 * NU>(glam + T * NX + t * 2 * NU, rp + C::oLU);
+                copy_slice<NU>(guhi + t * st_u, rp + C::oBU);
+                copy_slice<NU>(gulo + t * st_u, rp + C::oBL);
+                if (dyn) copy_slice<NX>(gc + t * NX, rp + C::oC);
+            }
+            if (with_residual) {
+                real W[SW][N], zt[N];
+                load_F_rows(dyn ? t : (T > 1 ? T - 2 : 0), W);
+                gload<N>(gz + t * N, zt);
+#pragma unroll
+                for (int s = 0; s < SW; ++s) {
+                    const int r = 4 * s + q;
+                    if ((4 * s + 3 < NX || r < NX) && active) {
+                        real xn = dyn ? gc[t * NX + r] : real(0);
+#pragma unroll
+                        for (int k = 0; k < N; ++k) xn = fma_(W[s][k], zt[k], xn);
+                        // row block T-1 holds the initial-state rows x_0 - x_init (al_utils.py:274)
+                        rp[C::oR + r] = dyn ? gz[(t + 1) * N + r] - xn : gz[r] - gx0[r];
+                    }
                 }
             }
         }
-#pragma unroll
-        for (int s = 0; s < SW; ++s) {
-            const int r = 4 * s + q;
-            if (r < NX && active) recp(T - 1)[C::oR + r] = gz[r] - gx0[r];
+    }
+    // Kernel end: the working copies of z and lam back to the caller's arrays.
+    __device__ __forceinline__ void stage_out() {
+        if (!active) return;
+#pragma unroll 2
+        for (int t = 0; t < T; ++t) {
+            const real *rp = recp(t);
+            copy_slice<N>(rp + C::oZ, gz + t * N);
+            copy_slice<NX>(rp + C::oLE, glam + t * NX);
+            copy_slice<2 * NU>(rp + C::oLU, glam + T * NX + t * 2 * NU);
         }
     }
 
     // ---- forward sweep: gradient, factorisation, forward substitution ------------------
-    __device__ __forceinline__ void forward(real *g_out) {
+    // With `pending`, the step alpha*d the previous line search chose (d is still in the
+    // records) is applied on the fly: z_t is read, advanced, used and written back here, which
+    // saves the separate pass (this sweep recomputes the equality residuals anyway).
+    __device__ __forceinline__ void forward(real *g_out, real alpha, bool pending) {
         real S[ST], Sy[SW];
         real vprev[NX], Syrep[NX];
 #pragma unroll
         for (int i = 0; i < ST; ++i) S[i] = 0;
 #pragma unroll
         for (int s = 0; s < SW; ++s) Sy[s] = 0;
-        if constexpr (C::DMA) issue_forward_dma(0);
         // stage 0: x_0 is pinned by the initial-state rows (eq row block T-1), al_utils.py:274
         {
             real z0[NX], xi[NX], li[NX];
-            gload<NX>(gz, z0);
+            gload<NX>(recp(0) + C::oZ, z0);
             gload<NX>(gx0, xi);
-            gload<NX>(glam + (T - 1) * NX, li);
+            gload<NX>(recp(T - 1) + C::oLE, li);
+            if (pending) {
+                real d0[NX];
+                gload<NX>(recp(0) + C::oY, d0);
+#pragma unroll
+                for (int j = 0; j < NX; ++j) z0[j] = fma_(alpha, d0[j], z0[j]);
+            }
 #pragma unroll
             for (int j = 0; j < NX; ++j) {
                 real r = z0[j] - xi[j];
@@ -517,60 +304,50 @@ struct Quad {
             real W[SW][N];
             real Y[N], D[N];
             real v[SW];
+            real zs[SY];
+#pragma unroll
+            for (int m = 0; m < SY; ++m) zs[m] = 0;
             real *rp = recp(t);
             // ---- loads (one batch) + residual + multiplier estimate
             {
                 real zt[N], Qt[N], qt[N];
                 real cs[SW], zn[SW], lm[SW];
                 real lu[NU], ll[NU], bu[NU], bl[NU];
-                if constexpr (C::DMA) {
-                    // the image of stage t has landed; the previous stage's record stores (at least
-                    // one per tile of L) were issued after its DMA and may still be in flight
-                    if (t == 0) dma_wait<0>();
-                    else dma_wait<SH * (SH + 1) / 2>();
-                    read_F_image(W);
+                gload<N>(rp + C::oZ, zt);
+                gload<N>(rp + C::oQ, Qt);
+                gload<N>(rp + C::oq, qt);
+                const int td = dyn ? t : (T > 1 ? T - 2 : 0);  // valid addresses for the last stage
+                load_F_rows(td, W);
+                const real *rn = recp(td + 1);
 #pragma unroll
-                    for (int k = 0; k < N; ++k) {
-                        zt[k] = small_rep<N, C::fZ>(k);
-                        Qt[k] = small_rep<N, C::fQ>(k);
-                        qt[k] = small_rep<N, C::fq>(k);
-                    }
-#pragma unroll
-                    for (int s = 0; s < SW; ++s) {
-                        cs[s] = small_own<NX, C::fC>(s);
-                        zn[s] = small_own<NX, C::fZN>(s);
-                        lm[s] = small_own<NX, C::fLE>(s);
-                    }
-#pragma unroll
-                    for (int j = 0; j < NU; ++j) {
-                        lu[j] = small_rep<2 * NU, C::fLU>(j);
-                        ll[j] = small_rep<2 * NU, C::fLU>(NU + j);
-                        bu[j] = small_rep<NU, C::fBU>(j);
-                        bl[j] = small_rep<NU, C::fBL>(j);
-                    }
-                    lds_reads_done();  // the image may be overwritten from here on
-                } else {
-                    gload<N>(gz + t * N, zt);
-                    gload<N>(gQd + t * N, Qt);
-                    gload<N>(gq + t * N, qt);
-                    const int td = dyn ? t : (T > 1 ? T - 2 : 0);  // valid addresses for the last stage
-                    load_F_rows(td, W);
-#pragma unroll
-                    for (int s = 0; s < SW; ++s) {
-                        const int r = 4 * s + q, rc = r < NX ? r : NX - 1;
-                        cs[s] = gc[td * NX + rc];
-                        zn[s] = gz[(td + 1) * N + rc];
-                        lm[s] = glam[td * NX + rc];
-                    }
-#pragma unroll
-                    for (int j = 0; j < NU; ++j) {
-                        lu[j] = glam[T * NX + t * 2 * NU + j];
-                        ll[j] = glam[T * NX + t * 2 * NU + NU + j];
-                        bu[j] = uhi(t, j);
-                        bl[j] = ulo(t, j);
-                    }
+                for (int s = 0; s < SW; ++s) {
+                    const int r = 4 * s + q, rc = r < NX ? r : NX - 1;
+                    cs[s] = rp[C::oC + rc];
+                    zn[s] = rn[C::oZ + rc];
+                    lm[s] = rp[C::oLE + rc];
                 }
-                ALQP_STAMP(0);  // forward: inputs in registers
+                gload<NU>(rp + C::oLU, lu);
+                gload<NU>(rp + C::oLU + NU, ll);
+                gload<NU>(rp + C::oBU, bu);
+                gload<NU>(rp + C::oBL, bl);
+                if (pending) {  // wave-uniform: z_t += alpha d_t, z_{t+1}[x] += alpha d_{t+1}[x]
+                    real dt[N], dn[SW];
+                    gload<N>(rp + C::oY, dt);
+#pragma unroll
+                    for (int s = 0; s < SW; ++s) dn[s] = rn[C::oY + ((4 * s + q < NX) ? 4 * s + q : NX - 1)];
+#pragma unroll
+                    for (int k = 0; k < N; ++k) zt[k] = fma_(alpha, dt[k], zt[k]);
+#pragma unroll
+                    for (int s = 0; s < SW; ++s) zn[s] = fma_(alpha, dn[s], zn[s]);
+                    // own elements of the advanced z_t; written with the stage results below (a
+                    // store here would sit between the loads and their counted waits)
+#pragma unroll
+                    for (int m = 0; m < SY; ++m)
+                        zs[m] = sel4(zt[4 * m], (4 * m + 1 < N) ? zt[(4 * m + 1 < N) ? 4 * m + 1 : 0] : real(0),
+                                     (4 * m + 2 < N) ? zt[(4 * m + 2 < N) ? 4 * m + 2 : 0] : real(0),
+                                     (4 * m + 3 < N) ? zt[(4 * m + 3 < N) ? 4 * m + 3 : 0] : real(0), q);
+                }
+                ALQP_STAMP(0);  // forward: exposed load latency
                 if (!dyn) {
 #pragma unroll
                     for (int s = 0; s < SW; ++s)
@@ -657,8 +434,6 @@ struct Quad {
                         for (int j = 0; j < 4 * s + 4; ++j)
                             if (j < N) H[C::hidx(s, j)] = fma_(fi, fr[j], H[C::hidx(s, j)]);
                     }
-                    // a slice of the next stage's DMA (dyn <=> there is a next stage)
-                    if constexpr (C::DMA) fwd_slot<(FWD_UNITS + NX - 1) / NX>(r, t + 1);
                 }
             }
             ALQP_STAMP(1);  // forward: residual, gradient, H assembly incl. F'F
@@ -708,6 +483,11 @@ struct Quad {
 #pragma unroll
                 for (int j = 0; j < N; ++j)
                     if ((j & 3) == q) rp[C::oY + j] = Y[j];
+                if (pending) {
+#pragma unroll
+                    for (int m = 0; m < SY; ++m)
+                        if (4 * m + 3 < N || 4 * m + q < N) rp[C::oZ + 4 * m + q] = zs[m];
+                }
             }
             // ---- carry to the next stage: replicated v = lam + rho r and W_t y_t
 #pragma unroll
@@ -715,75 +495,37 @@ struct Quad {
                 vprev[j] = qbv(v[j >> 2], j);
                 Syrep[j] = qbv(Sy[j >> 2], j);
             }
-            ALQP_STAMP(3);  // forward: stores issued
+            ALQP_STAMP(3);  // forward: stores drained
         }
     }
 
     // ---- backward sweep ---------------------------------------------------------------
     __device__ __forceinline__ void backward() {
-        constexpr int UPSB = (BWD_UNITS + 2 * N - 1) / (2 * N);  // DMA units per loop iteration
         real dxn[NX];
 #pragma unroll
         for (int j = 0; j < NX; ++j) dxn[j] = 0;
-        if constexpr (C::DMA) {
-            dma_wait();  // the forward sweep's stores of record T-1 are complete
-            issue_backward_dma(T - 1);
-        }
         for (int t = T - 1; t >= 0; --t) {
             const bool dyn = t < T - 1;
             real *rp = recp(t);
             real H[HT];
-            real yo[SY];
-            real W[SW][N];
-            if constexpr (C::DMA) {
-                // younger than the DMA of this stage: the SY stores of d_{t+1} (exactly SY, below)
-                if (t == T - 1) dma_wait<0>();
-                else dma_wait<SY>();
 #pragma unroll
-                for (int s = 0; s < SH; ++s)
+            for (int s = 0; s < SH; ++s)
 #pragma unroll
-                    for (int c = 0; c <= s; ++c) {
-                        const int ql = (C::lanes_of(s) == 4 || q < C::lanes_of(s)) ? q : 0;
-                        const float *src = lds + C::bR + ip * C::SR + C::oL + C::lbase(s) + c * 4 * C::lanes_of(s) + 4 * ql;
-                        const float4 v4 = *reinterpret_cast<const float4 *>(src);
-                        H[C::hidx(s, 4 * c)] = v4.x;
-                        H[C::hidx(s, 4 * c + 1)] = v4.y;
-                        H[C::hidx(s, 4 * c + 2)] = v4.z;
-                        H[C::hidx(s, 4 * c + 3)] = v4.w;
-                    }
-#pragma unroll
-                for (int m = 0; m < SY; ++m) {
-                    constexpr int NCHR = (C::oY + N) / 4;  // full chunks of the record segment
-                    const int e = C::oY + 4 * m + q;
-                    real v = lds[C::bR + ip * C::SR + e];
-                    if (C::oY + 4 * m + 3 >= 4 * NCHR) {
-                        const int et = e - 4 * NCHR;
-                        const real tv = lds[C::bRt + 4 * ip + (et >= 0 && et < 4 ? et : 0)];
-                        v = (et >= 0) ? tv : v;
-                    }
-                    yo[m] = (4 * m + q < N) ? v : real(0);
+                for (int c = 0; c <= s; ++c) {
+                    // lanes without a real row re-read lane 0's words (unconditional load, values unused)
+                    const int ql = (C::lanes_of(s) == 4 || q < C::lanes_of(s)) ? q : 0;
+                    gld4(rp + C::oL + C::lbase(s) + c * 4 * C::lanes_of(s) + 4 * ql, H[C::hidx(s, 4 * c)],
+                         H[C::hidx(s, 4 * c + 1)], H[C::hidx(s, 4 * c + 2)], H[C::hidx(s, 4 * c + 3)]);
                 }
-                read_F_image(W);
-                lds_reads_done();  // the image may be overwritten from here on
-                if (!dyn && t > 0) issue_backward_dma(t - 1);  // stage T-1 has no loops to spread it over
-            } else {
+            real yo[SY];
 #pragma unroll
-                for (int s = 0; s < SH; ++s)
-#pragma unroll
-                    for (int c = 0; c <= s; ++c) {
-                        // lanes without a real row re-read lane 0's words (unconditional load, values unused)
-                        const int ql = (C::lanes_of(s) == 4 || q < C::lanes_of(s)) ? q : 0;
-                        gld4(rp + C::oL + C::lbase(s) + c * 4 * C::lanes_of(s) + 4 * ql, H[C::hidx(s, 4 * c)],
-                             H[C::hidx(s, 4 * c + 1)], H[C::hidx(s, 4 * c + 2)], H[C::hidx(s, 4 * c + 3)]);
-                    }
-#pragma unroll
-                for (int m = 0; m < SY; ++m) yo[m] = (4 * m + q < N) ? rp[C::oY + 4 * m + q] : real(0);
-                load_F_rows(dyn ? t : (T > 1 ? T - 2 : 0), W);  // same batch as the record loads
-            }
+            for (int m = 0; m < SY; ++m) yo[m] = (4 * m + q < N) ? rp[C::oY + 4 * m + q] : real(0);
             real Y[N];
 #pragma unroll
             for (int j = 0; j < N; ++j) Y[j] = qbv(yo[j >> 2], j);
-            ALQP_STAMP(4);  // backward: inputs in registers
+            real W[SW][N];
+            load_F_rows(dyn ? t : (T > 1 ? T - 2 : 0), W);  // same batch as the record loads
+            ALQP_STAMP(4);  // backward: exposed load latency
             real dxs[SW];
 #pragma unroll
             for (int s = 0; s < SW; ++s)
@@ -799,7 +541,6 @@ struct Quad {
 #pragma unroll
                     for (int s = 0; s < SW; ++s) p = fma_(W[s][j], dxs[s], p);
                     vv[j] = qsum(p);
-                    if constexpr (C::DMA) { if (t > 0) bwd_slot<UPSB>(j, t - 1); }
                 }
                 // w = L^{-1} v
 #pragma unroll
@@ -808,7 +549,6 @@ struct Quad {
                     vv[j] = wj;
 #pragma unroll
                     for (int k = j + 1; k < N; ++k) vv[k] = fma_(-qbv(H[C::hidx(k >> 2, j)], k), wj, vv[k]);
-                    if constexpr (C::DMA) { if (t > 0) bwd_slot<UPSB>(N + j, t - 1); }
                 }
 #pragma unroll
                 for (int j = 0; j < N; ++j) Y[j] = fma_(rho, vv[j], Y[j]);
@@ -822,14 +562,9 @@ struct Quad {
                 for (int j = 0; j < i; ++j) Y[j] = fma_(-qbv(H[C::hidx(i >> 2, j)], i), di, Y[j]);
             }
             if (active) {
-                // own elements of d_t: one store instruction per slot (dma_wait<SY> counts them)
 #pragma unroll
-                for (int m = 0; m < SY; ++m) {
-                    const real dv = sel4(Y[4 * m], (4 * m + 1 < N) ? Y[(4 * m + 1 < N) ? 4 * m + 1 : 0] : real(0),
-                                         (4 * m + 2 < N) ? Y[(4 * m + 2 < N) ? 4 * m + 2 : 0] : real(0),
-                                         (4 * m + 3 < N) ? Y[(4 * m + 3 < N) ? 4 * m + 3 : 0] : real(0), q);
-                    if (4 * m + 3 < N || 4 * m + q < N) rp[C::oY + 4 * m + q] = dv;
-                }
+                for (int j = 0; j < N; ++j)
+                    if ((j & 3) == q) rp[C::oY + j] = Y[j];
             }
             if (dyn) {
 #pragma unroll
@@ -933,16 +668,16 @@ struct Quad {
 #pragma unroll
             for (int m = 0; m < SY; ++m) {
                 const int j = 4 * m + q, jc = (4 * m + 3 < N) ? j : (j < N ? j : N - 1);
-                zz[m] = gz[t * N + jc];
+                zz[m] = rp[C::oZ + jc];
                 dd[m] = rp[C::oY + jc];
-                QQ[m] = gQd[t * N + jc];
-                qq[m] = gq[t * N + jc];
+                QQ[m] = rp[C::oQ + jc];
+                qq[m] = rp[C::oq + jc];
                 if (m >= MU0) {
                     const int ju = jc >= NX ? jc - NX : 0;
-                    lu[m] = glam[T * NX + t * 2 * NU + ju];
-                    ll[m] = glam[T * NX + t * 2 * NU + NU + ju];
-                    bu[m] = uhi(t, ju);
-                    bl[m] = ulo(t, ju);
+                    lu[m] = rp[C::oLU + ju];
+                    ll[m] = rp[C::oLU + NU + ju];
+                    bu[m] = rp[C::oBU + ju];
+                    bl[m] = rp[C::oBL + ju];
                 }
             }
 #pragma unroll
@@ -950,7 +685,7 @@ struct Quad {
                 const int r = 4 * s + q, rc = (4 * s + 3 < NX) ? r : (r < NX ? r : NX - 1);
                 rv[s] = rp[C::oR + rc];
                 sv[s] = rp[C::oS + rc];
-                lv[s] = glam[t * NX + rc];
+                lv[s] = rp[C::oLE + rc];
             }
 #pragma unroll
             for (int m = 0; m < SY; ++m) {
@@ -997,16 +732,14 @@ struct Quad {
     // z += alpha d ; r += alpha s   (own elements only)
     __device__ __forceinline__ void apply_step(real alpha) {
         if (!active) return;
-        real *__restrict__ zp = gz;       // z and the workspace never overlap: lets the loads of
-        real *__restrict__ wp = rec;      // several stages leave before the first store
 #pragma unroll 4
-        for (int t = 0; t < T; ++t) {
-            real *__restrict__ rp = wp + (size_t)t * RECW;
+        for (int t = 0; t < T; ++t) {  // 4 stages of loads in flight per round trip
+            real *rp = recp(t);
             real zz[SY], dd[SY], rr[SW], ss[SW];
 #pragma unroll
             for (int m = 0; m < SY; ++m) {
                 const int j = 4 * m + q, jc = j < N ? j : N - 1;
-                zz[m] = zp[t * N + jc];
+                zz[m] = rp[C::oZ + jc];
                 dd[m] = rp[C::oY + jc];
             }
 #pragma unroll
@@ -1018,7 +751,7 @@ struct Quad {
 #pragma unroll
             for (int m = 0; m < SY; ++m) {
                 const int j = 4 * m + q;
-                if (j < N) zp[t * N + j] = fma_(alpha, dd[m], zz[m]);
+                if (j < N) rp[C::oZ + j] = fma_(alpha, dd[m], zz[m]);
             }
 #pragma unroll
             for (int s = 0; s < SW; ++s) {
@@ -1041,10 +774,10 @@ struct Quad {
             for (int m = 0; m < SY; ++m) {
                 const int j = 4 * m + q;
                 if (j < N) {
-                    real z = gz[t * N + j];
+                    real z = rp[C::oZ + j];
                     bad |= !(z - z == real(0));
                     if (j >= NX) {
-                        real cu = fmax_(z - uhi(t, j - NX), real(0)), cl = fmax_(ulo(t, j - NX) - z, real(0));
+                        real cu = fmax_(z - rp[C::oBU + j - NX], real(0)), cl = fmax_(rp[C::oBL + j - NX] - z, real(0));
                         acc += fma_(cu, cu, cl * cl);
                     }
                 }
@@ -1058,22 +791,22 @@ struct Quad {
     __device__ __forceinline__ void dual_update() {
         if (!active) return;
         for (int t = 0; t < T; ++t) {
-            const real *rp = recp(t);
+            real *rp = recp(t);
 #pragma unroll
             for (int s = 0; s < SW; ++s) {
                 const int r = 4 * s + q;
-                if (r < NX) glam[t * NX + r] = fma_(rho, rp[C::oR + r], glam[t * NX + r]);
+                if (r < NX) rp[C::oLE + r] = fma_(rho, rp[C::oR + r], rp[C::oLE + r]);
             }
 #pragma unroll
             for (int m = 0; m < SY; ++m) {
                 const int j = 4 * m + q;
                 if (j >= NX && j < N) {
                     const int ju = j - NX;
-                    real u = gz[t * N + j];
-                    real *lu = glam + T * NX + t * 2 * NU + ju, *ll = lu + NU;
-                    real a = fma_(rho, u - uhi(t, ju), *lu), c = fma_(rho, ulo(t, ju) - u, *ll);
-                    *lu = a < 0 ? real(0) : a;
-                    *ll = c < 0 ? real(0) : c;
+                    real u = rp[C::oZ + j];
+                    real a = fma_(rho, u - rp[C::oBU + ju], rp[C::oLU + ju]);
+                    real c = fma_(rho, rp[C::oBL + ju] - u, rp[C::oLU + NU + ju]);
+                    rp[C::oLU + ju] = a < 0 ? real(0) : a;
+                    rp[C::oLU + NU + ju] = c < 0 ? real(0) : c;
                 }
             }
         }

@@ -43,7 +43,7 @@ def test_supported_dims_and_lds_budget():
     assert lib.alqp_qps_per_wave(C.byref(_lib.AlqpDims(1, 5, 2, 1)), 0) == 4
     # quad variant workspace: one record per (instance, stage)
     w = lib.alqp_workspace_bytes(C.byref(_lib.AlqpDims(16384, 20, 13, 4)), 0)
-    assert w == 16384 * 20 * 232 * 4
+    assert w == 16384 * 20 * 352 * 4
     assert lib.alqp_workspace_bytes(C.byref(_lib.AlqpDims(4, 20, 7, 3)), 0) == 0
 
 

@@ -14,7 +14,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 NAMES = ["fwd load wait", "fwd assemble H", "fwd panel", "fwd stores drained", "bwd load wait",
-         "bwd solves+stores", "line-search merits", "pick+apply", "DMA issue (both sweeps)", "other (init, dual, exit)"]
+         "bwd solves+stores", "line-search merits", "pick+apply", "(unused)", "other (init, dual, exit)"]
 
 
 def main():
