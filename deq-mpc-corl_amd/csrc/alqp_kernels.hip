@@ -207,6 +207,10 @@ __global__ __launch_bounds__(64, 2) void k_solve_lin(SolveArgs<real> a, TraceArg
 #endif  // ALQP_BUILD_MAIN
 
 #if ALQP_BUILD_QUAD
+// line-search merits accumulated inside the backward sweep (1) or by a pass of their own (0)
+#ifndef ALQP_FUSE_LS
+#define ALQP_FUSE_LS 1
+#endif
 // ---- fused LinDx solve, quad variant (4 lanes per instance, HBM workspace) --------------
 #ifdef ALQP_PHASE_TIMING
 __device__ unsigned long long g_phase_cycles[10];
@@ -268,7 +272,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
             if constexpr (TRACE) tg = (tr.g && active) ? tr.g + ((size_t)step_id * a.B + b) * T * N : nullptr;
             QSTAMP(9);  // everything between Newton steps
             qd.forward(tg, alpha_pend, pend);
-            qd.backward();
+            real ph[20];
+            qd.template backward<ALQP_FUSE_LS>(ph);
             QSTAMP(-1);
             if constexpr (TRACE) {
                 if (tr.d && active) {
@@ -277,8 +282,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
                         for (int j = qd.q; j < N; j += 4) td[t * N + j] = qd.recp(t)[C::oY + j];
                 }
             }
-            real ph[20];
-            qd.template merit_candidates<20>(ph, false);
+            if constexpr (!ALQP_FUSE_LS) qd.template merit_candidates<20>(ph, false);
             QSTAMP(6);  // line-search candidates
             int kbest = 0;
             real best = ph[0];
@@ -353,7 +357,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     qd.rho = a.rho[b];
     qd.info = 0;
     qd.solve_forward(a.gbar + (size_t)b * T * N);
-    qd.backward();
+    real unused[20];
+    qd.template backward<false>(unused);
     if (active) {
         const real *zf = a.z_final + (size_t)b * T * N;
         real *qg = a.q_grad + (size_t)b * T * N;

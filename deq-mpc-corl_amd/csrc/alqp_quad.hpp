@@ -500,7 +500,19 @@ struct Quad {
     }
 
     // ---- backward sweep ---------------------------------------------------------------
-    __device__ __forceinline__ void backward() {
+    // LS: also accumulate the merit of the 20 line-search candidates z + 2^-k d while d_t and
+    // s_t = (J d)_t are in registers (algebra: merit_candidates below; the sum runs over the
+    // stages in sweep order T-1..0). The extra inputs sit in the record next to L and y.
+    template <bool LS>
+    __device__ __forceinline__ void backward(real (&phi)[20]) {
+        constexpr int MU0 = NX / 4;  // first element slot that can hold a control
+        real c0 = 0, c1 = 0, c2 = 0;
+        real acc[20];
+        real rvT[SW], lvT[SW];
+#pragma unroll
+        for (int k = 0; k < 20; ++k) acc[k] = 0;
+#pragma unroll
+        for (int s = 0; s < SW; ++s) rvT[s] = lvT[s] = 0;
         real dxn[NX];
 #pragma unroll
         for (int j = 0; j < NX; ++j) dxn[j] = 0;
@@ -525,6 +537,29 @@ struct Quad {
             for (int j = 0; j < N; ++j) Y[j] = qbv(yo[j >> 2], j);
             real W[SW][N];
             load_F_rows(dyn ? t : (T > 1 ? T - 2 : 0), W);  // same batch as the record loads
+            real zz[SY], QQ[SY], qq[SY], lu[SY], ll[SY], bu[SY], bl[SY], rv[SW], lv[SW];
+            if constexpr (LS) {
+#pragma unroll
+                for (int m = 0; m < SY; ++m) {
+                    const int j = 4 * m + q, jc = (4 * m + 3 < N) ? j : (j < N ? j : N - 1);
+                    zz[m] = rp[C::oZ + jc];
+                    QQ[m] = rp[C::oQ + jc];
+                    qq[m] = rp[C::oq + jc];
+                    if (m >= MU0) {
+                        const int ju = jc >= NX ? jc - NX : 0;
+                        lu[m] = rp[C::oLU + ju];
+                        ll[m] = rp[C::oLU + NU + ju];
+                        bu[m] = rp[C::oBU + ju];
+                        bl[m] = rp[C::oBL + ju];
+                    }
+                }
+#pragma unroll
+                for (int s = 0; s < SW; ++s) {
+                    const int r = 4 * s + q, rc = (4 * s + 3 < NX) ? r : (r < NX ? r : NX - 1);
+                    rv[s] = rp[C::oR + rc];
+                    lv[s] = rp[C::oLE + rc];
+                }
+            }
             ALQP_STAMP(4);  // backward: exposed load latency
             real dxs[SW];
 #pragma unroll
@@ -566,6 +601,9 @@ struct Quad {
                 for (int j = 0; j < N; ++j)
                     if ((j & 3) == q) rp[C::oY + j] = Y[j];
             }
+            real sv[SW];
+#pragma unroll
+            for (int s = 0; s < SW; ++s) sv[s] = 0;
             if (dyn) {
 #pragma unroll
                 for (int s = 0; s < SW; ++s) {
@@ -573,7 +611,52 @@ struct Quad {
                     real p = 0;
 #pragma unroll
                     for (int k = 0; k < N; ++k) p = fma_(W[s][k], Y[k], p);
-                    if (r < NX && active) rp[C::oS + r] = dxs[s] - p;
+                    sv[s] = dxs[s] - p;
+                    if (r < NX && active) rp[C::oS + r] = sv[s];
+                }
+            }
+            if constexpr (LS) {
+#pragma unroll
+                for (int m = 0; m < SY; ++m) {
+                    const int j = 4 * m + q;
+                    const real ok = (4 * m + 3 < N || j < N) ? real(1) : real(0);
+                    const real dj = sel4(Y[4 * m], (4 * m + 1 < N) ? Y[(4 * m + 1 < N) ? 4 * m + 1 : 0] : real(0),
+                                         (4 * m + 2 < N) ? Y[(4 * m + 2 < N) ? 4 * m + 2 : 0] : real(0),
+                                         (4 * m + 3 < N) ? Y[(4 * m + 3 < N) ? 4 * m + 3 : 0] : real(0), q);
+                    const real z = zz[m], d = dj * ok, Qv = QQ[m] * ok, qv = qq[m] * ok;
+                    c0 = fma_(fma_(real(0.5) * Qv, z, qv), z, c0);
+                    c1 = fma_(fma_(Qv, z, qv), d, c1);
+                    c2 = fma_(real(0.5) * Qv * d, d, c2);
+                    if (m >= MU0) {
+                        const real isu = (j >= NX && j < N) ? real(1) : real(0);
+                        real alpha = 1;
+#pragma unroll
+                        for (int k = 0; k < 20; ++k) {
+                            real zk = fma_(alpha, d, z);
+                            real vu = zk - bu[m], vl = bl[m] - zk;
+                            real cu = fmax_(vu, real(0)), cl = fmax_(vl, real(0));
+                            acc[k] = fma_(isu, fma_(lu[m], vu, ll[m] * vl) + real(0.5) * rho * fma_(cu, cu, cl * cl), acc[k]);
+                            alpha *= real(0.5);
+                        }
+                    }
+                }
+                if (dyn) {
+#pragma unroll
+                    for (int s = 0; s < SW; ++s) {
+                        const int r = 4 * s + q;
+                        const real ok = (4 * s + 3 < NX || r < NX) ? real(1) : real(0);
+                        const real rr = rv[s] * ok, ss = sv[s] * ok, lm = lv[s] * ok;
+                        c0 = fma_(fma_(real(0.5) * rho, rr, lm), rr, c0);
+                        c1 = fma_(fma_(rho, rr, lm), ss, c1);
+                        c2 = fma_(real(0.5) * rho * ss, ss, c2);
+                    }
+                } else {
+                    // row block T-1 holds the initial-state rows; their s = d_0[x] comes last
+#pragma unroll
+                    for (int s = 0; s < SW; ++s) {
+                        rvT[s] = rv[s];
+                        lvT[s] = lv[s];
+                    }
                 }
             }
 #pragma unroll
@@ -584,6 +667,29 @@ struct Quad {
 #pragma unroll
         for (int j = 0; j < NX; ++j)
             if ((j & 3) == q && active) recp(T - 1)[C::oS + j] = dxn[j];
+        if constexpr (LS) {
+#pragma unroll
+            for (int s = 0; s < SW; ++s) {
+                const int r = 4 * s + q;
+                const real ok = (4 * s + 3 < NX || r < NX) ? real(1) : real(0);
+                const real sj = sel4(dxn[4 * s], (4 * s + 1 < NX) ? dxn[(4 * s + 1 < NX) ? 4 * s + 1 : 0] : real(0),
+                                     (4 * s + 2 < NX) ? dxn[(4 * s + 2 < NX) ? 4 * s + 2 : 0] : real(0),
+                                     (4 * s + 3 < NX) ? dxn[(4 * s + 3 < NX) ? 4 * s + 3 : 0] : real(0), q);
+                const real rr = rvT[s] * ok, ss = sj * ok, lm = lvT[s] * ok;
+                c0 = fma_(fma_(real(0.5) * rho, rr, lm), rr, c0);
+                c1 = fma_(fma_(rho, rr, lm), ss, c1);
+                c2 = fma_(real(0.5) * rho * ss, ss, c2);
+            }
+            c0 = qsum(c0);
+            c1 = qsum(c1);
+            c2 = qsum(c2);
+            real alpha = 1;
+#pragma unroll
+            for (int k = 0; k < 20; ++k) {
+                phi[k] = qsum(acc[k]) + fma_(alpha, fma_(alpha, c2, c1), c0);
+                alpha *= real(0.5);
+            }
+        }
     }
 
     // ---- forward substitution only, with the factor of a previous solve still in the workspace:
