@@ -261,12 +261,19 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     int step_id = 0;
     bool pend = false;  // a chosen step not yet applied (the next forward sweep applies it)
     real alpha_pend = 0;
+    int bad = 0;
+    real rn2 = 0, phi_next = 0;
     for (int it = 0; it < a.al_iter; ++it) {
         if (a.flags & ALQP_INIT_MERIT) {
-            real p1[1];
-            qd.template merit_candidates<1>(p1, true);
-            phi_prev = p1[0];
+            if (it == 0) {
+                real p1[1];
+                qd.template merit_candidates<1>(p1, true);
+                phi_prev = p1[0];
+            } else {
+                phi_prev = phi_next;  // evaluated by iter_end() of the previous iteration
+            }
         }
+        pend = false;
         for (int st = 0; st < a.max_newton; ++st, ++step_id) {
             real *tg = nullptr;
             if constexpr (TRACE) tg = (tr.g && active) ? tr.g + ((size_t)step_id * a.B + b) * T * N : nullptr;
@@ -306,20 +313,20 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
                 }
             }
             const real alpha = acc ? real(1) / real(1 << kbest) : real(0);
-            pend = st + 1 < a.max_newton;
+            pend = true;  // applied by the next forward sweep or by iter_end()
             alpha_pend = alpha;
-            if (!pend) qd.apply_step(alpha);
-            QSTAMP(7);  // pick + apply
+            QSTAMP(7);  // pick
             phi_prev = best;  // merit <- new_merit even when rejected (al_utils.py:569)
         }
-        if (a.flags & ALQP_DUAL_UPDATE) {
-            qd.dual_update();
-            qd.rho *= a.rho_scale;
-        }
+        bad = 0;
+        qd.iter_end(alpha_pend, pend, (a.flags & ALQP_DUAL_UPDATE) != 0, (real)a.rho_scale, it + 1 == a.al_iter,
+                    phi_next, rn2, bad);
+        pend = false;
     }
-    int bad = 0;
-    const real rn2 = qd.rplus2(bad);
-    qd.stage_out();
+    if (a.al_iter <= 0) {
+        rn2 = qd.rplus2(bad);
+        qd.stage_out();
+    }
 #ifdef ALQP_PHASE_TIMING
     QSTAMP(9);
     if (lane == 0)

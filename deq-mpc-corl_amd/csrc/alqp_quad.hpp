@@ -835,7 +835,109 @@ struct Quad {
         }
     }
 
-    // z += alpha d ; r += alpha s   (own elements only)
+    // End of an AL iteration in ONE pass over the records (own elements only): apply the pending
+    // step (z += alpha d, r += alpha s), the dual update lam <- lam + rho r, bound rows clamped
+    // at 0, rho <- rho * scale (AL_mpc.py:315-317,325), the merit at the new (z, lam, rho) = the
+    // next iteration's starting merit (same expression order as merit_candidates<1>(., true)),
+    // ||r_+||^2 and the finiteness flag (al_utils.py:545-549); on the last iteration also the
+    // copy-out of z and lam.
+    __device__ __forceinline__ void iter_end(real alpha, bool pend, bool dual, real rho_scale, bool write_out,
+                                             real &phi_next, real &rn2, int &bad) {
+        constexpr int MU0 = NX / 4;
+        const real rho_n = dual ? rho * rho_scale : rho;
+        if (!pend) alpha = 0;
+        real c0 = 0, acc0 = 0, r2 = 0;
+#pragma unroll 2
+        for (int t = 0; t < T; ++t) {
+            real *rp = recp(t);
+            real zz[SY], dd[SY], QQ[SY], qq[SY];
+            real rv[SW], sv[SW], lv[SW];
+            real lu[SY], ll[SY], bu[SY], bl[SY];
+#pragma unroll
+            for (int m = 0; m < SY; ++m) {
+                const int j = 4 * m + q, jc = (4 * m + 3 < N) ? j : (j < N ? j : N - 1);
+                zz[m] = rp[C::oZ + jc];
+                dd[m] = rp[C::oY + jc];
+                QQ[m] = rp[C::oQ + jc];
+                qq[m] = rp[C::oq + jc];
+                if (m >= MU0) {
+                    const int ju = jc >= NX ? jc - NX : 0;
+                    lu[m] = rp[C::oLU + ju];
+                    ll[m] = rp[C::oLU + NU + ju];
+                    bu[m] = rp[C::oBU + ju];
+                    bl[m] = rp[C::oBL + ju];
+                }
+            }
+#pragma unroll
+            for (int s = 0; s < SW; ++s) {
+                const int r = 4 * s + q, rc = (4 * s + 3 < NX) ? r : (r < NX ? r : NX - 1);
+                rv[s] = rp[C::oR + rc];
+                sv[s] = rp[C::oS + rc];
+                lv[s] = rp[C::oLE + rc];
+            }
+#pragma unroll
+            for (int m = 0; m < SY; ++m) {
+                const int j = 4 * m + q;
+                const bool valid = 4 * m + 3 < N || j < N;
+                const real ok = valid ? real(1) : real(0);
+                const real z = pend ? fma_(alpha, dd[m], zz[m]) : zz[m];
+                const real Qv = QQ[m] * ok, qv = qq[m] * ok;
+                if (valid) bad |= !(z - z == real(0));
+                if (valid && active) {
+                    if (pend) rp[C::oZ + j] = z;
+                    if (write_out) gz[t * N + j] = z;
+                }
+                c0 = fma_(fma_(real(0.5) * Qv, z, qv), z, c0);
+                if (m >= MU0) {
+                    const bool isub = j >= NX && j < N;
+                    const real isu = isub ? real(1) : real(0);
+                    const int ju = isub ? j - NX : 0;
+                    const real vu = z - bu[m], vl = bl[m] - z;
+                    real lun = lu[m], lln = ll[m];
+                    if (dual) {
+                        const real a = fma_(rho, vu, lu[m]), c = fma_(rho, vl, ll[m]);
+                        lun = a < 0 ? real(0) : a;
+                        lln = c < 0 ? real(0) : c;
+                    }
+                    if (isub && active) {
+                        if (dual) {
+                            rp[C::oLU + ju] = lun;
+                            rp[C::oLU + NU + ju] = lln;
+                        }
+                        if (write_out) {
+                            glam[T * NX + t * 2 * NU + ju] = lun;
+                            glam[T * NX + t * 2 * NU + NU + ju] = lln;
+                        }
+                    }
+                    const real cu = fmax_(vu, real(0)), cl = fmax_(vl, real(0));
+                    acc0 = fma_(isu, fma_(lun, vu, lln * vl) + real(0.5) * rho_n * fma_(cu, cu, cl * cl), acc0);
+                    r2 = fma_(isu, fma_(cu, cu, cl * cl), r2);
+                }
+            }
+#pragma unroll
+            for (int s = 0; s < SW; ++s) {
+                const int r = 4 * s + q;
+                const bool valid = 4 * s + 3 < NX || r < NX;
+                const real ok = valid ? real(1) : real(0);
+                const real rn = pend ? fma_(alpha, sv[s], rv[s]) : rv[s];
+                const real ln = dual ? fma_(rho, rn, lv[s]) : lv[s];
+                if (valid && active) {
+                    if (pend) rp[C::oR + r] = rn;
+                    if (dual) rp[C::oLE + r] = ln;
+                    if (write_out) glam[t * NX + r] = ln;
+                }
+                const real rr = rn * ok, lm = ln * ok;
+                c0 = fma_(fma_(real(0.5) * rho_n, rr, lm), rr, c0);
+                r2 = fma_(rr, rr, r2);
+            }
+        }
+        rho = rho_n;
+        c0 = qsum(c0);
+        phi_next = qsum(acc0) + c0;
+        rn2 = qsum(r2);
+        bad = qor(bad);
+    }
+
     __device__ __forceinline__ void apply_step(real alpha) {
         if (!active) return;
 #pragma unroll 4
