@@ -82,6 +82,8 @@ __device__ inline float fmax_(float a, float b) { return __builtin_fmaxf(a, b); 
 __device__ inline double fmax_(double a, double b) { return __builtin_fmax(a, b); }
 __device__ inline float rsqrt_(float p) { return __builtin_amdgcn_rsqf(p); }
 __device__ inline double rsqrt_(double p) { return 1.0 / __builtin_sqrt(p); }
+__device__ inline float rcp_(float p) { return __builtin_amdgcn_rcpf(p); }
+__device__ inline double rcp_(double p) { return 1.0 / p; }
 
 // v if d >= 0 else +0, without a lane-mask compare (loop-invariant compares get hoisted
 // into SGPR pairs by the compiler and then spilled: 2 SGPRs per unrolled index)
