@@ -111,11 +111,6 @@ __device__ inline void gload(const real *p, real (&dst)[LEN]) {
     for (int c = (LEN / 4) * 4; c < LEN; ++c) dst[c] = p[c];
 }
 
-typedef float v4f __attribute__((ext_vector_type(4)));
-// v_mfma_f32_4x4x1_16b_f32: 16 blocks (block = lane / 4), D_i(lane q) = C_i(lane q) + A(lane i) * B(lane q)
-__device__ __forceinline__ v4f mfma44(float a, float b, v4f c) { return __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, c, 0, 0, 0); }
-__device__ __forceinline__ v4f mfma44(double, double, v4f c) { return c; }  // never instantiated for real work (fp64 keeps the VALU path)
-
 template <typename real, int NX_, int NU_>
 struct QCfg {
     static constexpr int NX = NX_, NU = NU_, N = NX_ + NU_;
@@ -136,7 +131,6 @@ struct QCfg {
         return o;
     }
     static constexpr int LW = lbase(SH);
-    static constexpr bool MFMA = sizeof(real) == 4;  // fp32: rank-1 tile updates on the matrix cores
     __host__ __device__ static constexpr int p4(int x) { return (x + 3) & ~3; }
     // The record also carries the stage's slice of every small per-stage array (working copies
     // of z and lam, copies of diag Q, q, c and the bounds): in their own arrays these are 52-68
@@ -175,7 +169,6 @@ struct Quad {
     __device__ __forceinline__ real uhi(int t, int j) const { return guhi[t * st_u + j]; }
     __device__ __forceinline__ real ulo(int t, int j) const { return gulo[t * st_u + j]; }
     __device__ __forceinline__ real *recp(int t) const { return rec + (size_t)t * RECW; }
-    __host__ __device__ static constexpr int tix(int s, int c) { return s * (s + 1) / 2 + c; }  // lower tile (s, c <= s)
 #ifdef ALQP_PHASE_TIMING
     // debug build only (tools/phase_timing.py): cycles per phase; a stamp drains the memory queue,
     // so "wait" buckets hold the exposed latency of the loads issued before them
@@ -281,10 +274,7 @@ struct Quad {
     // saves the separate pass (this sweep recomputes the equality residuals anyway).
     __device__ __forceinline__ void forward(real *g_out, real alpha, bool pending) {
         real S[ST], Sy[SW];
-        v4f St[SW * (SW + 1) / 2];  // Schur accumulator of the MFMA path (tiles)
         real vprev[NX], Syrep[NX];
-#pragma unroll
-        for (int i = 0; i < SW * (SW + 1) / 2; ++i) St[i] = v4f{0, 0, 0, 0};
 #pragma unroll
         for (int i = 0; i < ST; ++i) S[i] = 0;
 #pragma unroll
@@ -401,222 +391,103 @@ struct Quad {
                     if (g_out && (j & 3) == q) g_out[t * N + j] = g;
                 }
             }
-            if constexpr (C::MFMA) {
-                // ---- fp32: the stage's rank-1 updates on the matrix cores. v_mfma_f32_4x4x1 works
-                // on 16 independent 4x4 blocks, block = lane/4 = one instance: register i of lane q
-                // gets A(lane i) * B(lane q) added (tools/probes/mfma4x4_probe.hip). With rows dealt
-                // to lanes (row 4s+q) and four columns in a lane's register tuple, a 4x4 tile update
-                // T(s,c) += x_s y_c' takes B = x[4s+q] (the lane's own element) and A = y[4c+q]: both
-                // are already laid out that way, so the DPP broadcast per (pivot, column) pair and
-                // three quarters of the FMA issue slots of the VALU formulation disappear.
-                constexpr int NT = SH * (SH + 1) / 2, NTS = SW * (SW + 1) / 2;
-                v4f Ht[NT], Wt[SW][SH], Yt[SH];
+            // ---- H_tt rows (lower part, trimmed): diag + (1/rho) w_i w_j - Schur
+            real H[HT];
 #pragma unroll
-                for (int i = 0; i < NT; ++i) Ht[i] = v4f{0, 0, 0, 0};
+            for (int i = 0; i < HT; ++i) H[i] = 0;
 #pragma unroll
-                for (int s = 0; s < SH; ++s)
+            for (int s = 0; s < SH; ++s)
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) {
-                        Yt[s][c] = (4 * s + c < N) ? Y[(4 * s + c < N) ? 4 * s + c : 0] : real(0);
-                        // rows past N (last slot) get a unit diagonal: they stay decoupled and finite
-                        Ht[tix(s, s)][c] = (q == c) ? ((4 * s + c < N) ? D[(4 * s + c < N) ? 4 * s + c : 0] : real(1)) : real(0);
-                    }
-                // minus the Schur complement of stage t-1
-                if (t > 0) {
-#pragma unroll
-                    for (int s = 0; s < SW; ++s)
-#pragma unroll
-                        for (int c = 0; c <= s; ++c) Ht[tix(s, c)] -= St[tix(s, c)];
-                }
-#pragma unroll
-                for (int i = 0; i < NTS; ++i) St[i] = v4f{0, 0, 0, 0};
-#pragma unroll
-                for (int s = 0; s < SW; ++s) Sy[s] = 0;
-                // W <- -rho F_t as tiles (columns padded with zeros)
+                for (int c = 0; c < 4; ++c)
+                    if (4 * s + c < N) H[C::hidx(s, 4 * s + c)] = (q == c) ? D[4 * s + c] : real(0);
+            // minus the Schur complement of stage t-1 (its registers are dead afterwards: keeps
+            // the F'F phase below within the 256 architectural VGPRs)
+            if (t > 0) {
 #pragma unroll
                 for (int s = 0; s < SW; ++s)
 #pragma unroll
-                    for (int c = 0; c < SH; ++c)
+                    for (int b = 0; b < 4 * s + 4; ++b)
+                        if (b < NX) H[C::hidx(s, b)] -= S[C::hidx(s, b)];
+            }
 #pragma unroll
-                        for (int k = 0; k < 4; ++k)
-                            Wt[s][c][k] = (4 * c + k < N) ? -rho * W[s][(4 * c + k < N) ? 4 * c + k : 0] : real(0);
-                if (dyn) {
-                    // H += (1/rho) W'W: row r of W as a column-distributed vector (lane q: W[r][4s+q])
-                    const real irho = real(1) / rho;
+            for (int i = 0; i < ST; ++i) S[i] = 0;
 #pragma unroll
-                    for (int r = 0; r < NX; ++r) {
-                        real bs[SH];
+            for (int s = 0; s < SW; ++s) Sy[s] = 0;
+            // W <- -rho F_t  (the F'F term is then (1/rho) W'W)
 #pragma unroll
-                        for (int s = 0; s < SH; ++s) {
-                            const v4f rowt = Wt[r >> 2][s];
-                            bs[s] = sel4(qbv(rowt[0], r), qbv(rowt[1], r), qbv(rowt[2], r), qbv(rowt[3], r), q);
-                        }
+            for (int s = 0; s < SW; ++s)
 #pragma unroll
-                        for (int s = 0; s < SH; ++s) {
-                            const real bsc = bs[s] * irho;
+                for (int k = 0; k < N; ++k) W[s][k] *= -rho;
+            if (dyn) {
+                const real irho = real(1) / rho;
 #pragma unroll
-                            for (int c = 0; c <= s; ++c) Ht[tix(s, c)] = mfma44(bs[c], bsc, Ht[tix(s, c)]);
-                        }
-                    }
-                }
-                ALQP_STAMP(1);  // forward: residual, gradient, H assembly incl. F'F
-                // ---- right-looking root-free panel factorisation H = Lh D Lh' (see the VALU path)
-                real ipv[N];
+                for (int r = 0; r < NX; ++r) {
+                    real fr[N];
 #pragma unroll
-                for (int j = 0; j < N; ++j) {
-                    const int c0 = j >> 2, jj = j & 3;
-                    const real p = qbv(Ht[tix(c0, c0)][jj], j);
-                    if (!(p > 0) && info == 0) info = t * N + j + 1;
-                    const real ip = rcp_(p);
-                    ipv[j] = ip;
-                    // -Hh[.][j]/p_j as the A operand of column tile c; in the pivot's own tile only the
-                    // rows below the pivot (the finished columns must not be touched)
-                    real nl[SH];
+                    for (int j = 0; j < N; ++j) fr[j] = qbv(W[r >> 2][j], r);
 #pragma unroll
-                    for (int c = c0; c < SH; ++c) {
-                        const real lv_ = Ht[tix(c, c0)][jj] * ip;
-                        nl[c] = (c > c0 || q > jj) ? -lv_ : real(0);
-                    }
+                    for (int s = 0; s < SH; ++s) {
+                        real fi = sel4(fr[4 * s], (4 * s + 1 < N) ? fr[(4 * s + 1 < N) ? 4 * s + 1 : 0] : real(0),
+                                       (4 * s + 2 < N) ? fr[(4 * s + 2 < N) ? 4 * s + 2 : 0] : real(0),
+                                       (4 * s + 3 < N) ? fr[(4 * s + 3 < N) ? 4 * s + 3 : 0] : real(0), q) * irho;
 #pragma unroll
-                    for (int c = (jj == 3 ? c0 + 1 : c0); c < SH; ++c) {
-#pragma unroll
-                        for (int s = c; s < SH; ++s) Ht[tix(s, c)] = mfma44(nl[c], Ht[tix(s, c0)][jj], Ht[tix(s, c)]);
-#pragma unroll
-                        for (int s = 0; s < SW; ++s) Wt[s][c] = mfma44(nl[c], Wt[s][c0][jj], Wt[s][c]);
-                        Yt[c] = mfma44(nl[c], Yt[c0][jj], Yt[c]);
-                    }
-                    if (dyn) {
-                        real wa[SW];
-#pragma unroll
-                        for (int s = 0; s < SW; ++s) wa[s] = Wt[s][c0][jj] * ip;
-#pragma unroll
-                        for (int s = 0; s < SW; ++s) {
-#pragma unroll
-                            for (int cb = 0; cb <= s; ++cb) St[tix(s, cb)] = mfma44(wa[cb], Wt[s][c0][jj], St[tix(s, cb)]);
-                            Sy[s] = fma_(wa[s], Yt[c0][jj], Sy[s]);
-                        }
-                    }
-                }
-                // the solves multiply by 1/p_j: it takes the pivot's place on the diagonal
-#pragma unroll
-                for (int j = 0; j < N; ++j) Ht[tix(j >> 2, j >> 2)][j & 3] = (q == (j & 3)) ? ipv[j] : Ht[tix(j >> 2, j >> 2)][j & 3];
-                ALQP_STAMP(2);  // forward: panel
-                // ---- stage results -> workspace (each lane its own words)
-                if (active) {
-#pragma unroll
-                    for (int s = 0; s < SH; ++s)
-#pragma unroll
-                        for (int c = 0; c <= s; ++c)
-                            if (C::lanes_of(s) == 4 || q < C::lanes_of(s))
-                                gst4(rp + C::oL + C::lbase(s) + c * 4 * C::lanes_of(s) + 4 * q, Ht[tix(s, c)][0], Ht[tix(s, c)][1],
-                                     Ht[tix(s, c)][2], Ht[tix(s, c)][3]);
-#pragma unroll
-                    for (int j = 0; j < N; ++j)
-                        if ((j & 3) == q) rp[C::oY + j] = Yt[j >> 2][j & 3];
-                    if (pending) {
-#pragma unroll
-                        for (int m = 0; m < SY; ++m)
-                            if (4 * m + 3 < N || 4 * m + q < N) rp[C::oZ + 4 * m + q] = zs[m];
-                    }
-                }
-            } else {
-                // ---- H_tt rows (lower part, trimmed): diag + (1/rho) w_i w_j - Schur
-                real H[HT];
-#pragma unroll
-                for (int i = 0; i < HT; ++i) H[i] = 0;
-#pragma unroll
-                for (int s = 0; s < SH; ++s)
-#pragma unroll
-                    for (int c = 0; c < 4; ++c)
-                        if (4 * s + c < N) H[C::hidx(s, 4 * s + c)] = (q == c) ? D[4 * s + c] : real(0);
-                // minus the Schur complement of stage t-1 (its registers are dead afterwards: keeps
-                // the F'F phase below within the 256 architectural VGPRs)
-                if (t > 0) {
-#pragma unroll
-                    for (int s = 0; s < SW; ++s)
-#pragma unroll
-                        for (int b = 0; b < 4 * s + 4; ++b)
-                            if (b < NX) H[C::hidx(s, b)] -= S[C::hidx(s, b)];
-                }
-#pragma unroll
-                for (int i = 0; i < ST; ++i) S[i] = 0;
-#pragma unroll
-                for (int s = 0; s < SW; ++s) Sy[s] = 0;
-                // W <- -rho F_t  (the F'F term is then (1/rho) W'W)
-#pragma unroll
-                for (int s = 0; s < SW; ++s)
-#pragma unroll
-                    for (int k = 0; k < N; ++k) W[s][k] *= -rho;
-                if (dyn) {
-                    const real irho = real(1) / rho;
-#pragma unroll
-                    for (int r = 0; r < NX; ++r) {
-                        real fr[N];
-#pragma unroll
-                        for (int j = 0; j < N; ++j) fr[j] = qbv(W[r >> 2][j], r);
-#pragma unroll
-                        for (int s = 0; s < SH; ++s) {
-                            real fi = sel4(fr[4 * s], (4 * s + 1 < N) ? fr[(4 * s + 1 < N) ? 4 * s + 1 : 0] : real(0),
-                                           (4 * s + 2 < N) ? fr[(4 * s + 2 < N) ? 4 * s + 2 : 0] : real(0),
-                                           (4 * s + 3 < N) ? fr[(4 * s + 3 < N) ? 4 * s + 3 : 0] : real(0), q) * irho;
-#pragma unroll
-                            for (int j = 0; j < 4 * s + 4; ++j)
-                                if (j < N) H[C::hidx(s, j)] = fma_(fi, fr[j], H[C::hidx(s, j)]);
-                        }
-                    }
-                }
-                ALQP_STAMP(1);  // forward: residual, gradient, H assembly incl. F'F
-                // ---- right-looking root-free panel factorisation: H = Lh D Lh' with D = diag(p_j) the
-                // pivots and Lh unit lower. Column j is kept UNSCALED (Hh[k][j] = Lh[k][j] p_j) and
-                // 1/p_j takes the pivot's place: no square root, no column scaling, and the solves
-                // below use Hh[k][j] * (x_j / p_j).
-#pragma unroll
-                for (int j = 0; j < N; ++j) {
-                    const real p = qbv(H[C::hidx(j >> 2, j)], j);
-                    if (!(p > 0) && info == 0) info = t * N + j + 1;
-                    const real ip = rcp_(p);
-#pragma unroll
-                    for (int k = j + 1; k < N; ++k) {
-                        const real lkj = qbv(H[C::hidx(k >> 2, j)], k) * ip;
-#pragma unroll
-                        for (int s = (k >> 2); s < SH; ++s) H[C::hidx(s, k)] = fma_(-H[C::hidx(s, j)], lkj, H[C::hidx(s, k)]);
-#pragma unroll
-                        for (int s = 0; s < SW; ++s) W[s][k] = fma_(-W[s][j], lkj, W[s][k]);
-                        Y[k] = fma_(-Y[j], lkj, Y[k]);
-                    }
-                    if (dyn) {
-#pragma unroll
-                        for (int b = 0; b < NX; ++b) {
-                            const real wbj = qbv(W[b >> 2][j], b) * ip;
-#pragma unroll
-                            for (int s = (b >> 2); s < SW; ++s) S[C::hidx(s, b)] = fma_(W[s][j], wbj, S[C::hidx(s, b)]);
-                        }
-                        const real yip = Y[j] * ip;
-#pragma unroll
-                        for (int s = 0; s < SW; ++s) Sy[s] = fma_(W[s][j], yip, Sy[s]);
-                    }
-                    H[C::hidx(j >> 2, j)] = (q == (j & 3)) ? ip : H[C::hidx(j >> 2, j)];
-                }
-                ALQP_STAMP(2);  // forward: panel
-                // ---- stage results -> workspace (each lane its own words)
-                if (active) {
-#pragma unroll
-                    for (int s = 0; s < SH; ++s)
-#pragma unroll
-                        for (int c = 0; c <= s; ++c)
-                            if (C::lanes_of(s) == 4 || q < C::lanes_of(s))
-                                gst4(rp + C::oL + C::lbase(s) + c * 4 * C::lanes_of(s) + 4 * q, H[C::hidx(s, 4 * c)],
-                                     H[C::hidx(s, 4 * c + 1)], H[C::hidx(s, 4 * c + 2)], H[C::hidx(s, 4 * c + 3)]);
-#pragma unroll
-                    for (int j = 0; j < N; ++j)
-                        if ((j & 3) == q) rp[C::oY + j] = Y[j];
-                    if (pending) {
-#pragma unroll
-                        for (int m = 0; m < SY; ++m)
-                            if (4 * m + 3 < N || 4 * m + q < N) rp[C::oZ + 4 * m + q] = zs[m];
+                        for (int j = 0; j < 4 * s + 4; ++j)
+                            if (j < N) H[C::hidx(s, j)] = fma_(fi, fr[j], H[C::hidx(s, j)]);
                     }
                 }
             }
+            ALQP_STAMP(1);  // forward: residual, gradient, H assembly incl. F'F
+            // ---- right-looking root-free panel factorisation: H = Lh D Lh' with D = diag(p_j) the
+            // pivots and Lh unit lower. Column j is kept UNSCALED (Hh[k][j] = Lh[k][j] p_j) and
+            // 1/p_j takes the pivot's place: no square root, no column scaling, and the solves
+            // below use Hh[k][j] * (x_j / p_j).
+#pragma unroll
+            for (int j = 0; j < N; ++j) {
+                const real p = qbv(H[C::hidx(j >> 2, j)], j);
+                if (!(p > 0) && info == 0) info = t * N + j + 1;
+                const real ip = rcp_(p);
+#pragma unroll
+                for (int k = j + 1; k < N; ++k) {
+                    const real lkj = qbv(H[C::hidx(k >> 2, j)], k) * ip;
+#pragma unroll
+                    for (int s = (k >> 2); s < SH; ++s) H[C::hidx(s, k)] = fma_(-H[C::hidx(s, j)], lkj, H[C::hidx(s, k)]);
+#pragma unroll
+                    for (int s = 0; s < SW; ++s) W[s][k] = fma_(-W[s][j], lkj, W[s][k]);
+                    Y[k] = fma_(-Y[j], lkj, Y[k]);
+                }
+                if (dyn) {
+#pragma unroll
+                    for (int b = 0; b < NX; ++b) {
+                        const real wbj = qbv(W[b >> 2][j], b) * ip;
+#pragma unroll
+                        for (int s = (b >> 2); s < SW; ++s) S[C::hidx(s, b)] = fma_(W[s][j], wbj, S[C::hidx(s, b)]);
+                    }
+                    const real yip = Y[j] * ip;
+#pragma unroll
+                    for (int s = 0; s < SW; ++s) Sy[s] = fma_(W[s][j], yip, Sy[s]);
+                }
+                H[C::hidx(j >> 2, j)] = (q == (j & 3)) ? ip : H[C::hidx(j >> 2, j)];
+            }
+            ALQP_STAMP(2);  // forward: panel
+            // ---- stage results -> workspace (each lane its own words)
+            if (active) {
+#pragma unroll
+                for (int s = 0; s < SH; ++s)
+#pragma unroll
+                    for (int c = 0; c <= s; ++c)
+                        if (C::lanes_of(s) == 4 || q < C::lanes_of(s))
+                            gst4(rp + C::oL + C::lbase(s) + c * 4 * C::lanes_of(s) + 4 * q, H[C::hidx(s, 4 * c)],
+                                 H[C::hidx(s, 4 * c + 1)], H[C::hidx(s, 4 * c + 2)], H[C::hidx(s, 4 * c + 3)]);
+#pragma unroll
+                for (int j = 0; j < N; ++j)
+                    if ((j & 3) == q) rp[C::oY + j] = Y[j];
+                if (pending) {
+#pragma unroll
+                    for (int m = 0; m < SY; ++m)
+                        if (4 * m + 3 < N || 4 * m + q < N) rp[C::oZ + 4 * m + q] = zs[m];
+                }
+            }
+        
             // ---- carry to the next stage: replicated v = lam + rho r and W_t y_t
 #pragma unroll
             for (int j = 0; j < NX; ++j) {
