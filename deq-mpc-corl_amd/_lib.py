@@ -33,6 +33,7 @@ class AlqpTrace(C.Structure):
 ALQP_INIT_MERIT = 1
 ALQP_DUAL_UPDATE = 2
 ALQP_SAVE_FACTOR = 4
+ALQP_WS_PRIMED = 8
 VARIANT_AUTO, VARIANT_TEAM, VARIANT_QUAD = 0, 1, 2
 
 ERRORS = {-1: "bad argument", -2: "unsupported (nx, nu) or horizon does not fit in LDS",

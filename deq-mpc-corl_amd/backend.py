@@ -104,6 +104,7 @@ class HipBackend:
                     raise ValueError("mi_alqp: workspace too small")
             else:
                 ws, ws_bytes = self._workspace(dims, z)
+        self.last_variant = "quad" if vnum == 2 else "team"
         p = _lib.AlqpParams(al_iter, max_newton, n_ls, flags, rho_scale, vnum)
         tr = None
         if trace is not None:

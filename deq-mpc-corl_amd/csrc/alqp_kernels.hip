@@ -221,6 +221,8 @@ __device__ unsigned long long g_phase_cycles[10];
 template <typename real, int NX, int NU, bool TRACE>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_solve_lin_quad(SolveArgs<real> a, TraceArgs<real> tr, real *ws) {
     using C = QCfg<real, NX, NU>;
+    // fp64 is short of registers already: its line search keeps a pass of its own
+    constexpr bool FUSE_LS = ALQP_FUSE_LS && sizeof(real) == 4;
     constexpr int N = C::N;
     const int lane = threadIdx.x, qi = lane >> 2;
     const int b_raw = blockIdx.x * 16 + qi;
@@ -256,7 +258,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     for (int i = 0; i < 10; ++i) qd.tacc[i] = 0;
 #endif
     QSTAMP(-1);
-    qd.stage_in((a.flags & ALQP_INIT_MERIT) || a.max_newton == 0 || a.al_iter == 0);
+    if (!(a.flags & ALQP_WS_PRIMED)) qd.stage_in((a.flags & ALQP_INIT_MERIT) || a.max_newton == 0 || a.al_iter == 0);
 
     int step_id = 0;
     bool pend = false;  // a chosen step not yet applied (the next forward sweep applies it)
@@ -280,7 +282,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
             QSTAMP(9);  // everything between Newton steps
             qd.forward(tg, alpha_pend, pend);
             real ph[20];
-            qd.template backward<ALQP_FUSE_LS>(ph);
+            qd.template backward<FUSE_LS>(ph);
             QSTAMP(-1);
             if constexpr (TRACE) {
                 if (tr.d && active) {
@@ -289,7 +291,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
                         for (int j = qd.q; j < N; j += 4) td[t * N + j] = qd.recp(t)[C::oY + j];
                 }
             }
-            if constexpr (!ALQP_FUSE_LS) qd.template merit_candidates<20>(ph, false);
+            if constexpr (!FUSE_LS) qd.template merit_candidates<20>(ph, false);
             QSTAMP(6);  // line-search candidates
             int kbest = 0;
             real best = ph[0];

@@ -350,12 +350,14 @@ class MPC(Module):
             return MAX_NEWTON
         be.solve_lin(dims, Qd, q, F, c, st.x0, lo, hi, sb, stt, st.z, st.lam, st.rho, ws["phi"],
                      al_iter=1, max_newton=0, flags=_abi.ALQP_INIT_MERIT, **common)
+        primed = _abi.ALQP_WS_PRIMED if (getattr(be, "last_variant", None) == "quad" and not fl_save) else 0
         old = self._global_norm(ws["rn2"])
         n = 0
         while n < MAX_NEWTON:
             n += 1
+            # same workspace as the launch before, nothing touched in between: no copy-in pass
             be.solve_lin(dims, Qd, q, F, c, st.x0, lo, hi, sb, stt, st.z, st.lam, st.rho, ws["phi"],
-                         factor=ws.get("factor"), al_iter=1, max_newton=1, flags=fl_save, **common)
+                         factor=ws.get("factor"), al_iter=1, max_newton=1, flags=fl_save | primed, **common)
             new = self._global_norm(ws["rn2"])
             if new < 1e-3 or abs(old - new) / new < 1e-3:
                 break

@@ -49,6 +49,9 @@ typedef struct AlqpDims {
 #define ALQP_INIT_MERIT   1  /* evaluate merit(z) at the start of every AL iteration (al_utils.py:481) */
 #define ALQP_DUAL_UPDATE  2  /* lam += rho*r, clamp, rho *= rho_scale after the Newton steps (AL_mpc.py:315-325) */
 #define ALQP_SAVE_FACTOR  4  /* write the factor of the last executed Newton step to factor_out */
+#define ALQP_WS_PRIMED    8  /* quad variant: the workspace still holds this solve's records from the previous
+                               launch on it (same z, lam, Qd, q, c, bounds as the arrays passed now): skip the
+                               copy-in pass. Only for back-to-back launches of one solve, see INTEGRATION.md */
 
 typedef struct AlqpParams {
     int al_iter;      /* AL outer iterations done by this call (AL_mpc.py:290) */

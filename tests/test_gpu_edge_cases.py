@@ -141,6 +141,26 @@ def test_one_launch_equals_step_by_step_launches(variant):
     assert torch.equal(rho, rhof)
 
 
+def test_primed_workspace_skips_copy_in():
+    """ALQP_WS_PRIMED (quad): a Newton-step launch that follows another launch of the same solve on
+    the same workspace may skip the copy-in pass; the results are bit-identical to the unprimed
+    sequence, and the arrays (z, lam) stay in sync with the records after every launch."""
+    from deq_mpc_corl_amd import synthetic_problem
+    from deq_mpc_corl_amd import _lib
+    dt = torch.float32
+    p = synthetic_problem(40, 10, 13, 4, seed=14, dtype=dt, device=DEV, active=True)
+    outs = []
+    for primed in (0, _lib.ALQP_WS_PRIMED):
+        z, lam, rho, phi, *_ = solve(p, dt, "quad", al_iter=1, max_newton=0, flags=1)
+        for _ in range(3):
+            z, lam, rho, phi, *_ = solve(p, dt, "quad", al_iter=1, max_newton=1, flags=primed, z=z, lam=lam, rho=rho, phi=phi)
+        z, lam, rho, phi, *_ = solve(p, dt, "quad", al_iter=1, max_newton=0, flags=2, z=z, lam=lam, rho=rho, phi=phi)
+        outs.append((z.clone(), lam.clone(), rho.clone(), phi.clone()))
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+    assert float((outs[0][0] - p.z0).abs().max()) > 1e-3  # the steps did move z
+
+
 def test_streaming_mode_matches_cpu_host_logic():
     """warm_start_initialize + al_solve_stream semantics (AL_mpc.py:342-423, 581-592) on the GPU
     backend against the same host logic driven by the test-only oracle backend: lamda zeroed,
