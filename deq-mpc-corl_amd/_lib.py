@@ -13,7 +13,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libmi_alqp.so")
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 
 class AlqpDims(C.Structure):
@@ -22,7 +22,8 @@ class AlqpDims(C.Structure):
 
 class AlqpParams(C.Structure):
     _fields_ = [("al_iter", C.c_int), ("max_newton", C.c_int), ("n_ls", C.c_int),
-                ("flags", C.c_int), ("rho_scale", C.c_double), ("variant", C.c_int)]
+                ("flags", C.c_int), ("rho_scale", C.c_double), ("variant", C.c_int),
+                ("skip_flag", C.c_void_p)]
 
 
 class AlqpTrace(C.Structure):
@@ -61,6 +62,7 @@ _PLAIN = {
     "alqp_lds_bytes": (C.c_size_t, [C.POINTER(AlqpDims), C.c_int]),
     "alqp_qps_per_wave": (C.c_int, [C.POINTER(AlqpDims), C.c_int]),
     "alqp_workspace_bytes": (C.c_size_t, [C.POINTER(AlqpDims), C.c_int]),
+    "alqp_exit_test": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_void_p]),
 }
 
 EXPORTED_SYMBOLS = sorted([f"{n}_{s}" for n in _SIGS for s in ("f32", "f64")] + list(_PLAIN))

@@ -83,7 +83,7 @@ class HipBackend:
     def solve_lin(self, dims, Qd, q, F, c, x0, ulo, uhi, sb_u, st_u, z, lam, rho, phi,
                   rnorm2=None, info=None, status=None, factor=None, al_iter=2, max_newton=4,
                   n_ls=20, flags=_lib.ALQP_INIT_MERIT | _lib.ALQP_DUAL_UPDATE, rho_scale=10.0,
-                  trace=None, variant=None, workspace=None):
+                  trace=None, variant=None, workspace=None, skip=None):
         """variant: None/"auto" (quad unless a factor must be saved), "team", "quad".
         workspace: a dedicated scratch tensor for the quad variant (kept by the caller when
         the factor it holds afterwards is needed for `backward_ws`); default: a cached one."""
@@ -105,7 +105,8 @@ class HipBackend:
             else:
                 ws, ws_bytes = self._workspace(dims, z)
         self.last_variant = "quad" if vnum == 2 else "team"
-        p = _lib.AlqpParams(al_iter, max_newton, n_ls, flags, rho_scale, vnum)
+        skp = _ptr(skip, "skip", torch.float64, True)
+        p = _lib.AlqpParams(al_iter, max_newton, n_ls, flags, rho_scale, vnum, skp.value if skp is not None else None)
         tr = None
         if trace is not None:
             tr = _lib.AlqpTrace(*[
@@ -120,6 +121,13 @@ class HipBackend:
                 _ptr(factor, "factor", dt, True), C.byref(tr) if tr is not None else None,
                 _ptr(ws, "workspace", dt, True), ws_bytes, _stream())
         _lib.check(rc, "alqp_solve_lin_" + sfx)
+
+    def exit_test(self, sumsq, ctl, mode, tol=1e-3):
+        """Device-side batch-global exit test (alqp_exit_test): sumsq 0-d/1-elem float64 tensor,
+        ctl float64[3] = {done, steps, old_norm}; nothing is synchronised."""
+        rc = self.lib.alqp_exit_test(_ptr(sumsq, "sumsq", torch.float64), _ptr(ctl, "ctl", torch.float64),
+                                     int(mode), float(tol), _stream())
+        _lib.check(rc, "alqp_exit_test")
 
     def newton_step(self, dims, z, xnext, F, x0, lam, rho, Qd, q, ulo, uhi, sb_u, st_u, d_out,
                     g_out=None, factor=None, info=None):

@@ -34,6 +34,7 @@ struct SolveArgs {
     int *info;
     unsigned char *status;
     real *factor;
+    const double *skip;  // nullable: *skip != 0 -> the launch does nothing (device-side loop exit)
 };
 
 template <typename real>
@@ -70,6 +71,7 @@ __device__ inline unsigned opaque_zero() {
 // ---- fused LinDx solve -------------------------------------------------------------
 template <typename real, int NX, int NU, bool TRACE>
 __global__ __launch_bounds__(64, 2) void k_solve_lin(SolveArgs<real> a, TraceArgs<real> tr) {
+    if (a.skip && *a.skip != 0.0) return;  // block-uniform, before any barrier
     using C = Cfg<real, NX, NU>;
     constexpr int G = C::G, N = C::N;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -224,6 +226,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     // fp64 is short of registers already: its line search keeps a pass of its own
     constexpr bool FUSE_LS = ALQP_FUSE_LS && sizeof(real) == 4;
     constexpr int N = C::N;
+    if (a.skip && *a.skip != 0.0) return;  // wave-uniform
     const int lane = threadIdx.x, qi = lane >> 2;
     const int b_raw = blockIdx.x * 16 + qi;
     const bool active = b_raw < a.B;
@@ -740,6 +743,7 @@ int solve_lin_impl(const AlqpDims *dims, const AlqpParams *prm, const void *Qd, 
     a.sb_u = sb_u; a.st_u = st_u;
     a.z = (real *)z; a.lam = (real *)lam; a.rho = (real *)rho; a.phi = (real *)phi;
     a.rnorm2 = (real *)rnorm2; a.info = info; a.status = status; a.factor = (real *)factor_out;
+    a.skip = prm->skip_flag;
     TraceArgs<real> tr = {};
     if (trace) {
         tr.g = (real *)trace->g; tr.d = (real *)trace->d; tr.phi = (real *)trace->phi;
@@ -849,6 +853,21 @@ int dual_impl(const AlqpDims *dims, const void *z, const void *xnext, const void
     return hipGetLastError() == hipSuccess ? 0 : ALQP_E_LAUNCH;
 }
 
+// batch-global exit test of the Newton loop, taken on the device (al_utils.py:551-564)
+__global__ void k_exit_test(const double *sumsq, double *ctl, int mode, double tol) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const double nw = sqrt(sumsq[0]);
+    if (mode == 0) {
+        ctl[0] = 0.0;
+        ctl[1] = 0.0;
+        ctl[2] = nw;
+    } else if (ctl[0] == 0.0) {
+        ctl[1] += 1.0;
+        const double old = ctl[2];
+        if (nw < tol || fabs(old - nw) / nw < tol) ctl[0] = 1.0;
+        else ctl[2] = nw;
+    }
+}
 #endif  // ALQP_BUILD_MAIN
 
 }  // namespace alqp
@@ -857,7 +876,13 @@ int dual_impl(const AlqpDims *dims, const void *z, const void *xnext, const void
 #if ALQP_BUILD_MAIN
 extern "C" {
 
-int alqp_abi_version(void) { return 3; }
+int alqp_abi_version(void) { return 4; }
+
+int alqp_exit_test(const double *sumsq, double *ctl, int mode, double tol, void *stream) {
+    if (!sumsq || !ctl || (mode != 0 && mode != 1)) return ALQP_E_BADARG;
+    hipLaunchKernelGGL(alqp::k_exit_test, dim3(1), dim3(64), 0, (hipStream_t)stream, sumsq, ctl, mode, tol);
+    return hipGetLastError() == hipSuccess ? 0 : ALQP_E_LAUNCH;
+}
 
 size_t alqp_workspace_bytes(const AlqpDims *dims, int is_f64) {
     if (!alqp::dims_ok(dims)) return 0;

@@ -295,6 +295,16 @@ class MPC(Module):
             return torch.full((B,), float(r), dtype=dtype, device=device)
         return r.to(device=device, dtype=dtype).reshape(B).contiguous().clone()
 
+    def _global_sumsq(self, rn2):
+        """sum_b sum_rows r+^2 as a 1-element float64 device tensor (all-reduced over the ranks
+        of a sharded batch); nothing is synchronised with the host."""
+        s = rn2.sum(dtype=torch.float64).reshape(1)
+        if self.process_group is not None or (
+                torch.distributed.is_available() and torch.distributed.is_initialized()
+                and getattr(self, "sync_global_exit", False)):
+            torch.distributed.all_reduce(s, group=self.process_group)
+        return s
+
     def _global_norm(self, rn2):
         """sqrt(sum_b sum_rows r+^2): the batch-global quantity the reference exits on
         (torch.norm(dyn_res).item(), al_utils.py:486,552). With a sharded batch the
@@ -343,26 +353,37 @@ class MPC(Module):
             common["variant"] = "quad"
             need_factor = False
         fl_save = _abi.ALQP_SAVE_FACTOR if need_factor else 0
+        wsx = common.get("workspace")
+        if wsx is None and hasattr(be, "_workspace"):
+            wsx = be._workspace(dims, st.z)[0]   # the cached scratch a quad launch will use
+        # ALQP_WS_PRIMED bookkeeping: ws["primed"] is the workspace whose records hold THIS
+        # solve's current z/lam (written by the previous quad launch), else None
+        def pflag():
+            return _abi.ALQP_WS_PRIMED if (wsx is not None and ws.get("primed") is wsx) else 0
+        def after():
+            ws["primed"] = wsx if getattr(be, "last_variant", None) == "quad" else None
         if self.exit_mode == "fixed":
             be.solve_lin(dims, Qd, q, F, c, st.x0, lo, hi, sb, stt, st.z, st.lam, st.rho, ws["phi"],
                          factor=ws.get("factor"), al_iter=1, max_newton=MAX_NEWTON,
-                         flags=_abi.ALQP_INIT_MERIT | fl_save, **common)
+                         flags=_abi.ALQP_INIT_MERIT | fl_save | (0 if fl_save else pflag()), **common)
+            after()
             return MAX_NEWTON
         be.solve_lin(dims, Qd, q, F, c, st.x0, lo, hi, sb, stt, st.z, st.lam, st.rho, ws["phi"],
-                     al_iter=1, max_newton=0, flags=_abi.ALQP_INIT_MERIT, **common)
-        primed = _abi.ALQP_WS_PRIMED if (getattr(be, "last_variant", None) == "quad" and not fl_save) else 0
-        old = self._global_norm(ws["rn2"])
-        n = 0
-        while n < MAX_NEWTON:
-            n += 1
+                     al_iter=1, max_newton=0, flags=_abi.ALQP_INIT_MERIT | pflag(), **common)
+        after()
+        # The reference's batch-global exit test (al_utils.py:551-564) is taken on the device: all
+        # MAX_NEWTON launches are enqueued, each one a no-op once ctl[0] is set, and the number of
+        # executed steps (ctl[1]) is read back once per solve. No host round trip per Newton step.
+        ctl = torch.zeros(3, dtype=torch.float64, device=st.z.device)
+        be.exit_test(self._global_sumsq(ws["rn2"]), ctl, 0)
+        for _ in range(MAX_NEWTON):
             # same workspace as the launch before, nothing touched in between: no copy-in pass
             be.solve_lin(dims, Qd, q, F, c, st.x0, lo, hi, sb, stt, st.z, st.lam, st.rho, ws["phi"],
-                         factor=ws.get("factor"), al_iter=1, max_newton=1, flags=fl_save | primed, **common)
-            new = self._global_norm(ws["rn2"])
-            if new < 1e-3 or abs(old - new) / new < 1e-3:
-                break
-            old = new
-        return n
+                         factor=ws.get("factor"), al_iter=1, max_newton=1,
+                         flags=fl_save | (0 if fl_save else pflag()), skip=ctl, **common)
+            after()
+            be.exit_test(self._global_sumsq(ws["rn2"]), ctl, 1)
+        return ctl
 
     def _newton_al_nonlin(self, st, Qd, q, bnd, ws, need_factor):
         """NewtonAL.forward (al_utils.py:451-576) with `dx`/`dx_jac` as PyTorch calls
@@ -492,15 +513,19 @@ class MPC(Module):
                 if F is not None and not linearize_once:
                     # (never on the private workspace: its y/r/s slots may be rewritten, its L not,
                     #  but keep the saved factor's workspace out of later launches altogether)
+                    wsc = be._workspace(dims, st.z)[0] if hasattr(be, "_workspace") else None
+                    pf = _abi.ALQP_WS_PRIMED if (wsc is not None and ws.get("primed") is wsc) else 0
                     be.solve_lin(dims, Qd, q, F, c, st.x0, lo, hi, sb, stt, st.z, st.lam, st.rho,
                                  ws["phi"], rnorm2=ws["rn2"], info=None, status=ws["status"],
-                                 al_iter=1, max_newton=0, n_ls=N_LS, flags=_abi.ALQP_DUAL_UPDATE,
+                                 al_iter=1, max_newton=0, n_ls=N_LS, flags=_abi.ALQP_DUAL_UPDATE | pf,
                                  rho_scale=RHO_SCALE)
+                    ws["primed"] = wsc if getattr(be, "last_variant", None) == "quad" else None
                 else:
                     xn = true_next(st.z)
                     be.merit(dims, 1, st.z, xn, st.x0, st.lam, st.rho, Qd, q, lo, hi, sb, stt,
                              ws["phi"], ws["rn2"])
                     be.dual_update(dims, st.z, xn, st.x0, lo, hi, sb, stt, st.lam, st.rho, RHO_SCALE)
+                    ws["primed"] = None   # lam/rho changed behind the workspace records' back
                 if stream:
                     if linearize_once:
                         mean = float(ws["rn2"].sqrt().mean().item())
@@ -511,6 +536,11 @@ class MPC(Module):
                         break
             if stream and float(st.rho.max().item()) > self.rho_max:
                 st.status_flag = True
+        # device-side exit counters (one read-back for the whole solve)
+        if any(torch.is_tensor(v) for v in npa):
+            vals = torch.stack([v[1] if torch.is_tensor(v) else torch.tensor(float(v), dtype=torch.float64, device=st.z.device)
+                                for v in npa]).tolist()
+            npa = [int(round(v)) for v in vals]
         st.newton_per_al = npa
         self.last_status = ws["status"].bool()
         self.last_info = ws["info"]

@@ -62,6 +62,9 @@ typedef struct AlqpParams {
     int variant;      /* kernel variant of alqp_solve_lin: 0 auto, 1 team (factor in LDS, no
                          workspace), 2 quad (4 lanes per instance, factor streamed through the
                          HBM workspace; no ALQP_SAVE_FACTOR) */
+    const double *skip_flag; /* nullable DEVICE pointer: when *skip_flag != 0 at launch time the call
+                         does nothing at all (ctl[0] of alqp_exit_test: the batch-global exit of the
+                         reference's Newton loop taken on the device, no host round trip) */
 } AlqpParams;
 
 /* optional per-step trace (all nullable, for tests): S = al_iter*max_newton steps */
@@ -191,6 +194,18 @@ int alqp_backward_ws_f64(const AlqpDims *dims, void *workspace, size_t ws_bytes,
                          void *Qd_grad, void *stream);
 
 /* Library/ABI version, bumped when a signature changes. */
+/*
+ * The reference leaves its Newton loop on a BATCH-GLOBAL test (al_utils.py:486,551-564):
+ * new = ||r_+||_F over the whole batch; stop when new < tol or |old - new| / new < tol.
+ * This entry point takes that decision on the device so that the host can enqueue all Newton-step
+ * launches of an AL iteration without synchronising: sumsq[0] = sum_b rnorm2[b] (the caller
+ * reduces, and all-reduces over ranks when the batch is sharded), ctl = {done, steps, old_norm}.
+ *   mode 0: ctl <- {0, 0, sqrt(sumsq)}                       (before the first step)
+ *   mode 1: if (!done) { steps++; new = sqrt(sumsq); done = the test above; else old = new }
+ * Pass ctl as AlqpParams.skip_flag of the following launches.
+ */
+int alqp_exit_test(const double *sumsq, double *ctl, int mode, double tol, void *stream);
+
 int alqp_abi_version(void);
 
 #ifdef __cplusplus

@@ -31,9 +31,25 @@ class OracleBackend:
     def supported(self, B, T, nx, nu, dtype):
         return True
 
+    def exit_test(self, sumsq, ctl, mode, tol=1e-3):
+        """CPU twin of alqp_exit_test (include/mi_alqp.h)."""
+        import math
+        nw = math.sqrt(float(sumsq[0]))
+        if mode == 0:
+            ctl[0], ctl[1], ctl[2] = 0.0, 0.0, nw
+        elif float(ctl[0]) == 0.0:
+            ctl[1] += 1.0
+            old = float(ctl[2])
+            if nw < tol or (nw == nw and abs(old - nw) / nw < tol if nw != 0 else False):
+                ctl[0] = 1.0
+            else:
+                ctl[2] = nw
+
     def solve_lin(self, dims, Qd, q, F, c, x0, ulo, uhi, sb_u, st_u, z, lam, rho, phi, rnorm2=None,
                   info=None, status=None, factor=None, al_iter=2, max_newton=4, n_ls=20, flags=3,
-                  rho_scale=10.0, trace=None, variant=None):
+                  rho_scale=10.0, trace=None, variant=None, skip=None):
+        if skip is not None and float(skip[0]) != 0.0:
+            return
         B, T, nx, nu = dims
         s = _sfx(z)
         npdt = np.float64 if s == "f64" else np.float32

@@ -14,7 +14,7 @@ class CallableOnly:
 
 out = []
 for dt, name in ((torch.float32, "f32"), (torch.float64, "f64")):
-    B, T, nx, nu = 16384, 20, 13, 4
+    B, T, nx, nu = int(os.environ.get("MODES_B", "16384")), 20, 13, 4
     p = synthetic_problem(B, T, nx, nu, seed=0, dtype=dt, device=dev)
     dyn = AffineDynamics(p.F, p.c)
     cost = QuadCost(torch.diag_embed(p.Qd), p.q, torch.zeros(B, T, device=dev, dtype=dt))
