@@ -46,6 +46,11 @@ class HipBackend:
 
     name = "hip"
     default_variant = "auto"
+    # "auto": the quad variant (16 instances per wavefront, factor streamed through HBM) wins once
+    # the batch fills the chip; below that the team variant (one instance per lane team, factor in
+    # LDS) has 2-2.4x lower latency (measured on MI355X at (13,4) T=20: B=128 0.83 vs 1.94 ms,
+    # B=4096 2.11 vs 2.08 ms, B=16384 8.2 vs 3.4 ms; (8,2) T=10 crosses near B=5000)
+    QUAD_MIN_BATCH = 4096
 
     def __init__(self):
         self.lib = _lib.load()
@@ -95,7 +100,7 @@ class HipBackend:
             variant = self.default_variant
         vnum = {"auto": 0, "team": 1, "quad": 2}[variant]
         if vnum == 0:
-            vnum = 1 if (flags & _lib.ALQP_SAVE_FACTOR) else 2
+            vnum = 1 if ((flags & _lib.ALQP_SAVE_FACTOR) or B < self.QUAD_MIN_BATCH) else 2
         ws, ws_bytes = (None, 0)
         if vnum == 2:
             if workspace is not None:

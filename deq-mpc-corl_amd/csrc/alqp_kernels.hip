@@ -752,8 +752,10 @@ int solve_lin_impl(const AlqpDims *dims, const AlqpParams *prm, const void *Qd, 
     // variant: 1 = team (factor in LDS), 2 = quad (4 lanes/instance, HBM workspace), 0 = auto
     const size_t need = quad_ws_bytes<real>(dims->nx, dims->nu, dims->B, dims->T);
     int variant = prm->variant;
+    // auto: quad once the batch fills the chip (16 instances per wavefront, 1024 SIMDs), team below
+    // (2-2.4x lower latency at small batches; measured crossover at (13,4) T=20: B = 4096)
     if (variant == 0)
-        variant = (need > 0 && workspace && ws_bytes >= need && !(prm->flags & ALQP_SAVE_FACTOR)) ? 2 : 1;
+        variant = (need > 0 && workspace && ws_bytes >= need && !(prm->flags & ALQP_SAVE_FACTOR) && dims->B >= 4096) ? 2 : 1;
     if (variant == 2) {
         if (prm->flags & ALQP_SAVE_FACTOR) return ALQP_E_UNSUPPORTED;
         if (need == 0) return ALQP_E_UNSUPPORTED;

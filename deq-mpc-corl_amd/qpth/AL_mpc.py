@@ -447,8 +447,8 @@ class MPC(Module):
               "info": torch.zeros(B, dtype=torch.int32, device=dev),
               "status": torch.ones(B, dtype=torch.uint8, device=dev)}
         lin = st.lin
-        use_qws = need_grad and hasattr(be, "backward_ws") and (lin is not None or
-                                                                (bool(self.linearize_once) and st.stream_mode))
+        use_qws = need_grad and hasattr(be, "backward_ws") and B >= getattr(be, "QUAD_MIN_BATCH", 0) and (
+            lin is not None or (bool(self.linearize_once) and st.stream_mode))
         if use_qws:
             ws["qws"] = be.new_workspace(dims, st.z)
         elif need_grad:
