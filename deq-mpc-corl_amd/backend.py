@@ -127,6 +127,22 @@ class HipBackend:
                 _ptr(ws, "workspace", dt, True), ws_bytes, _stream())
         _lib.check(rc, "alqp_solve_lin_" + sfx)
 
+    def dyn_pendulum1l(self, x, u, h, want_jac=True):
+        """pendulum1l provider (alqp_dyn_pendulum1l): x [K,2], u [K,1], h float or [K(,1)] tensor
+        -> xnext [K,2], F [K,2,3] or None."""
+        K = x.shape[0]
+        dt = x.dtype
+        xn = torch.empty(K, 2, dtype=dt, device=x.device)
+        F = torch.empty(K, 2, 3, dtype=dt, device=x.device) if want_jac else None
+        hpt = h.to(dt).reshape(-1).contiguous() if torch.is_tensor(h) else None
+        if hpt is not None and hpt.numel() != K:
+            raise ValueError("mi_alqp: h must be a number or one value per point")
+        fn = getattr(self.lib, "alqp_dyn_pendulum1l_" + _dt(x))
+        rc = fn(K, _ptr(x, "x", dt), _ptr(u, "u", dt), 0.0 if hpt is not None else float(h), _ptr(hpt, "h", dt, True),
+                _ptr(xn, "xnext", dt), _ptr(F, "F", dt, True), _stream())
+        _lib.check(rc, "alqp_dyn_pendulum1l")
+        return xn, F
+
     def exit_test(self, sumsq, ctl, mode, tol=1e-3):
         """Device-side batch-global exit test (alqp_exit_test): sumsq 0-d/1-elem float64 tensor,
         ctl float64[3] = {done, steps, old_norm}; nothing is synchronised."""

@@ -855,6 +855,60 @@ int dual_impl(const AlqpDims *dims, const void *z, const void *xnext, const void
     return hipGetLastError() == hipSuccess ? 0 : ALQP_E_LAUNCH;
 }
 
+// ---- dynamics provider: pendulum1l (deqmpc/my_envs/pendulum1l/src/generated_dynamics.c:55-140,
+//      generated_derivatives.c:52-222). One RK4 step of theta'' = 4 tau - 19.62 sin(theta) with the
+//      tangents w.r.t. (theta, omega, tau) carried along; one point per lane, outputs in the
+//      solver's packed layout (x_next, F = [A | B] row-major 2x3). HBM-bound: 12 words per point.
+template <typename real>
+struct Dual3 {
+    real v, d0, d1, d2;
+};
+template <typename real>
+__device__ __forceinline__ Dual3<real> dadd(Dual3<real> a, real s, Dual3<real> b) {  // a + s b
+    return {fma_(s, b.v, a.v), fma_(s, b.d0, a.d0), fma_(s, b.d1, a.d1), fma_(s, b.d2, a.d2)};
+}
+template <typename real>
+__device__ __forceinline__ Dual3<real> pend_acc(Dual3<real> th, Dual3<real> ta) {
+    const real sn = sin(th.v), cs = cos(th.v);
+    const real kt = real(4), kg = real(19.62);
+    return {kt * ta.v - kg * sn, kt * ta.d0 - kg * cs * th.d0, kt * ta.d1 - kg * cs * th.d1, kt * ta.d2 - kg * cs * th.d2};
+}
+template <typename real>
+__global__ __launch_bounds__(256) void k_dyn_pendulum1l(long K, const real *x, const real *u, real h, const real *hpt, real *xn, real *F) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= K) return;
+    if (hpt) h = hpt[i];
+    using D = Dual3<real>;
+    const D th = {x[2 * i], 1, 0, 0}, om = {x[2 * i + 1], 0, 1, 0}, ta = {u[i], 0, 0, 1};
+    const real hh = real(0.5) * h;
+    const D k1t = om, k1o = pend_acc(th, ta);
+    const D om2 = dadd(om, hh, k1o), k2o = pend_acc(dadd(th, hh, k1t), ta);
+    const D om3 = dadd(om, hh, k2o), k3o = pend_acc(dadd(th, hh, om2), ta);
+    const D om4 = dadd(om, h, k3o), k4o = pend_acc(dadd(th, h, om3), ta);
+    const real two = real(2), h6 = h / real(6);
+    const D st = dadd(dadd(k1t, two, om2), real(1), dadd(om4, two, om3));
+    const D so = dadd(dadd(k1o, two, k2o), real(1), dadd(k4o, two, k3o));
+    const D tn = dadd(th, h6, st), on = dadd(om, h6, so);
+    if (xn) {
+        xn[2 * i] = tn.v;
+        xn[2 * i + 1] = on.v;
+    }
+    if (F) {
+        real *f = F + 6 * i;
+        f[0] = tn.d0; f[1] = tn.d1; f[2] = tn.d2;
+        f[3] = on.d0; f[4] = on.d1; f[5] = on.d2;
+    }
+}
+
+template <typename real>
+int dyn_pendulum1l_impl(long K, const void *x, const void *u, double h, const void *hpt, void *xn, void *F, void *stream) {
+    if (K < 0 || !x || !u || (!xn && !F)) return ALQP_E_BADARG;
+    if (K == 0) return 0;
+    hipLaunchKernelGGL(k_dyn_pendulum1l<real>, dim3((unsigned)((K + 255) / 256)), dim3(256), 0, (hipStream_t)stream, K,
+                       (const real *)x, (const real *)u, (real)h, (const real *)hpt, (real *)xn, (real *)F);
+    return hipGetLastError() == hipSuccess ? 0 : ALQP_E_LAUNCH;
+}
+
 // batch-global exit test of the Newton loop, taken on the device (al_utils.py:551-564)
 __global__ void k_exit_test(const double *sumsq, double *ctl, int mode, double tol) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
@@ -879,6 +933,13 @@ __global__ void k_exit_test(const double *sumsq, double *ctl, int mode, double t
 extern "C" {
 
 int alqp_abi_version(void) { return 4; }
+
+int alqp_dyn_pendulum1l_f32(long K, const void *x, const void *u, double h, const void *h_pt, void *xnext, void *F, void *stream) {
+    return alqp::dyn_pendulum1l_impl<float>(K, x, u, h, h_pt, xnext, F, stream);
+}
+int alqp_dyn_pendulum1l_f64(long K, const void *x, const void *u, double h, const void *h_pt, void *xnext, void *F, void *stream) {
+    return alqp::dyn_pendulum1l_impl<double>(K, x, u, h, h_pt, xnext, F, stream);
+}
 
 int alqp_exit_test(const double *sumsq, double *ctl, int mode, double tol, void *stream) {
     if (!sumsq || !ctl || (mode != 0 && mode != 1)) return ALQP_E_BADARG;

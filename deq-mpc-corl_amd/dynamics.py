@@ -1,0 +1,51 @@
+"""Dynamics providers that run as HIP kernels (no PyTorch round trip between Newton steps).
+
+`Pendulum1lDynamics` mirrors the reference's `my_envs.dynamics.Dynamics` / `CartpoleDynamics`
+family for the one-link pendulum package (deqmpc/my_envs/dynamics.py:15-75,
+my_envs/pendulum1l/src/dynamics.cpp:13-47): state x = (theta, omega), action u = tau, one RK4
+step of length dt; `jac` returns the next state and (A, B) like the `dx_jac` callables the MPC
+takes (al_utils.py:237-248). fp64 or fp32 on a ROCm device only: no CPU fallback.
+"""
+import torch
+
+from .backend import default_backend
+
+
+class Pendulum1lDynamics:
+    nx, nu = 2, 1
+
+    def __init__(self, dt=0.05, backend=None):
+        self.dt = float(dt)
+        self.backend = backend
+
+    def _be(self):
+        if self.backend is None:
+            self.backend = default_backend()
+        return self.backend
+
+    def __call__(self, x, u):
+        xn, _ = self._be().dyn_pendulum1l(x.contiguous(), u.contiguous(), self.dt, want_jac=False)
+        return xn
+
+    def jac(self, x, u):
+        xn, F = self._be().dyn_pendulum1l(x.contiguous(), u.contiguous(), self.dt, want_jac=True)
+        return xn, (F[..., :2], F[..., 2:])
+
+
+class pendulum1l:
+    """Module-shaped twin of the reference's compiled `pendulum1l` package
+    (my_envs/pendulum1l/src/dynamics.cpp:49-53: `dynamics`, `derivatives`), for
+    `Dynamics.package` (my_envs/dynamics.py:60-75): same argument order, shapes and return lists."""
+
+    @staticmethod
+    def dynamics(q_in, qdot_in, tau_in, h_in):
+        be = default_backend()
+        xn, _ = be.dyn_pendulum1l(torch.cat((q_in, qdot_in), 1).contiguous(), tau_in.contiguous(), h_in, want_jac=False)
+        return [xn[:, :1].contiguous(), xn[:, 1:].contiguous()]
+
+    @staticmethod
+    def derivatives(q_in, qdot_in, tau_in, h_in):
+        be = default_backend()
+        _, F = be.dyn_pendulum1l(torch.cat((q_in, qdot_in), 1).contiguous(), tau_in.contiguous(), h_in, want_jac=True)
+        # (dq'/dq, dq'/dqdot, dq'/dtau, dqdot'/dq, dqdot'/dqdot, dqdot'/dtau), each [bsz, 1, 1]
+        return [F[:, i, j].reshape(-1, 1, 1).contiguous() for i in (0, 1) for j in (0, 1, 2)]

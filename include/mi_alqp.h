@@ -206,6 +206,19 @@ int alqp_backward_ws_f64(const AlqpDims *dims, void *workspace, size_t ws_bytes,
  */
 int alqp_exit_test(const double *sumsq, double *ctl, int mode, double tol, void *stream);
 
+/*
+ * Dynamics provider for the nonlinear-caller mode, pendulum1l: replaces the reference's
+ * CasADi-generated pair dynamics(q, qdot, tau, h) / derivatives(...) (deqmpc/my_envs/pendulum1l/
+ * src/dynamics.cpp:13-47, generated_dynamics.c:55-140, generated_derivatives.c:52-222) with one
+ * kernel that emits the MPC's packed operands: one RK4 step of theta'' = 4 tau - 19.62 sin(theta)
+ * and its exact Jacobian.
+ *   in : x[K][2] = (theta, omega), u[K][1] = tau, step length h, or h_pt[K] per point when not
+ *        NULL (the reference passes a [bsz,1] tensor filled with dt, my_envs/dynamics.py:58)
+ *   out: xnext[K][2] (nullable), F[K][2][3] = [A | B] (nullable: dynamics only)
+ */
+int alqp_dyn_pendulum1l_f32(long K, const void *x, const void *u, double h, const void *h_pt, void *xnext, void *F, void *stream);
+int alqp_dyn_pendulum1l_f64(long K, const void *x, const void *u, double h, const void *h_pt, void *xnext, void *F, void *stream);
+
 int alqp_abi_version(void);
 
 #ifdef __cplusplus

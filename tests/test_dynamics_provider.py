@@ -1,0 +1,140 @@
+"""pendulum1l dynamics provider: the oracle restatement against vectors
+produced by the reference's own CasADi-generated code (tests/golden/dyn_pendulum1l.npz,
+tools/gen_dyn_golden.py), and the HIP kernel against both."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import dyn_py
+
+GOLD = np.load(os.path.join(os.path.dirname(__file__), "golden", "dyn_pendulum1l.npz"))
+
+
+@pytest.mark.parametrize("tag", ["h05", "h01"])
+def test_restatement_matches_reference_vectors(tag):
+    xn, A, B = dyn_py.pendulum1l(GOLD["x"], GOLD["u"], float(GOLD[tag + "_h"]))
+    assert np.abs(xn - GOLD[tag + "_xn"]).max() < 5e-14   # omega reaches 25: relative 2e-15
+    assert np.abs(A - GOLD[tag + "_A"]).max() < 1e-14
+    assert np.abs(B - GOLD[tag + "_B"]).max() < 1e-14
+
+
+def test_restatement_jacobian_is_the_derivative_of_the_step():
+    """Independent of the goldens: central differences of the step itself."""
+    x, u, h = GOLD["x"][:64], GOLD["u"][:64], 0.05
+    _, A, B = dyn_py.pendulum1l(x, u, h)
+    eps = 1e-6
+    for j in range(2):
+        dx = np.zeros_like(x); dx[:, j] = eps
+        num = (dyn_py.pendulum1l(x + dx, u, h)[0] - dyn_py.pendulum1l(x - dx, u, h)[0]) / (2 * eps)
+        assert np.abs(num - A[:, :, j]).max() < 1e-7
+    du = np.full_like(u, eps)
+    num = (dyn_py.pendulum1l(x, u + du, h)[0] - dyn_py.pendulum1l(x, u - du, h)[0]) / (2 * eps)
+    assert np.abs(num - B[:, :, 0]).max() < 1e-7
+
+
+@pytest.mark.skipif(not dyn_py.have_ref(), reason="oracle/_ref not built (no /root/reference here)")
+def test_compiled_reference_reproduces_its_fixture():
+    xn, A, B = dyn_py.pendulum1l_ref(GOLD["x"][:32], GOLD["u"][:32], 0.05)
+    assert np.array_equal(xn, GOLD["h05_xn"][:32]) and np.array_equal(A, GOLD["h05_A"][:32])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype,tol", [(torch.float64, 5e-13), (torch.float32, 2e-5)])
+@pytest.mark.parametrize("tag", ["h05", "h01"])
+def test_hip_provider_matches_reference_vectors(dtype, tol, tag):
+    from deq_mpc_corl_amd import Pendulum1lDynamics
+    dev = "cuda:0"
+    x = torch.tensor(GOLD["x"], dtype=dtype, device=dev)
+    u = torch.tensor(GOLD["u"], dtype=dtype, device=dev)
+    dyn = Pendulum1lDynamics(dt=float(GOLD[tag + "_h"]))
+    xn, (A, B) = dyn.jac(x, u)
+    xo = dyn(x, u)
+    torch.cuda.synchronize()
+    scale = 1.0 + np.abs(GOLD[tag + "_xn"])
+    assert (np.abs(xn.cpu().numpy() - GOLD[tag + "_xn"]) / scale).max() < tol
+    assert np.abs(A.cpu().numpy() - GOLD[tag + "_A"]).max() < tol
+    assert np.abs(B.cpu().numpy() - GOLD[tag + "_B"]).max() < tol
+    assert torch.equal(xo, xn)
+
+
+@pytest.mark.gpu
+def test_hip_provider_ragged_sizes_and_cpu_tensors_fail_loudly():
+    from deq_mpc_corl_amd import Pendulum1lDynamics
+    dyn = Pendulum1lDynamics(dt=0.05)
+    for K in (1, 255, 257, 1000):
+        x = torch.randn(K, 2, dtype=torch.float64, device="cuda:0")
+        u = torch.randn(K, 1, dtype=torch.float64, device="cuda:0")
+        xn, (A, B) = dyn.jac(x, u)
+        o = dyn_py.pendulum1l(x.cpu().numpy(), u.cpu().numpy(), 0.05)
+        assert np.abs(xn.cpu().numpy() - o[0]).max() < 1e-12 and np.abs(A.cpu().numpy() - o[1]).max() < 1e-12
+        assert A.shape == (K, 2, 2) and B.shape == (K, 2, 1)
+    with pytest.raises(RuntimeError):
+        dyn(torch.zeros(4, 2, dtype=torch.float64), torch.zeros(4, 1, dtype=torch.float64))
+
+
+@pytest.mark.gpu
+def test_package_twin_has_the_reference_signature():
+    """dynamics(q, qdot, tau, h[bsz,1]) -> [q', qdot'], derivatives(...) -> six [bsz,1,1] blocks in
+    the order of my_envs/pendulum1l/src/dynamics_cpu.cpp:81-107."""
+    from deq_mpc_corl_amd.dynamics import pendulum1l
+    dev = "cuda:0"
+    x = torch.tensor(GOLD["x"], dtype=torch.float64, device=dev)
+    u = torch.tensor(GOLD["u"], dtype=torch.float64, device=dev)
+    h = torch.full((x.shape[0], 1), 0.05, dtype=torch.float64, device=dev)
+    qn, qdn = pendulum1l.dynamics(x[:, :1].contiguous(), x[:, 1:].contiguous(), u, h)
+    assert qn.shape == (x.shape[0], 1)
+    assert np.abs(torch.cat((qn, qdn), 1).cpu().numpy() - GOLD["h05_xn"]).max() < 5e-13
+    J = pendulum1l.derivatives(x[:, :1].contiguous(), x[:, 1:].contiguous(), u, h)
+    assert len(J) == 6 and all(j.shape == (x.shape[0], 1, 1) for j in J)
+    assert np.abs(J[1].cpu().numpy()[:, 0, 0] - GOLD["h05_A"][:, 0, 1]).max() < 5e-13   # dq'/dqdot
+    assert np.abs(J[5].cpu().numpy()[:, 0, 0] - GOLD["h05_B"][:, 1, 0]).max() < 5e-13   # dqdot'/dtau
+
+
+@pytest.mark.gpu
+def test_mpc_nonlinear_mode_with_the_hip_provider():
+    """The drop-in MPC in nonlinear-caller mode driven by the kernel provider: same result as
+    with an equivalent PyTorch implementation of the same dynamics (autograd Jacobians)."""
+    from deq_mpc_corl_amd import MPC, QuadCost, Pendulum1lDynamics
+    dev, dt = "cuda:0", torch.float64
+    B, T = 48, 8
+    g = torch.Generator().manual_seed(5)
+    x0 = torch.stack([torch.rand(B, generator=g) * 2 - 1, torch.randn(B, generator=g)], 1).to(dt).to(dev)
+    Qd = torch.tensor([10.0, 1.0, 0.1], dtype=dt, device=dev).expand(B, T, 3).contiguous()
+    q = torch.zeros(B, T, 3, dtype=dt, device=dev)
+    h = 0.05
+
+    def f_torch(x, u):
+        def acc(th):
+            return 4.0 * u[:, 0] - 19.62 * torch.sin(th)
+        th, om = x[:, 0], x[:, 1]
+        k1t, k1o = om, acc(th)
+        k2t, k2o = om + 0.5 * h * k1o, acc(th + 0.5 * h * k1t)
+        k3t, k3o = om + 0.5 * h * k2o, acc(th + 0.5 * h * k2t)
+        k4t, k4o = om + h * k3o, acc(th + h * k3t)
+        return torch.stack([th + h / 6 * (k1t + 2 * k2t + 2 * k3t + k4t), om + h / 6 * (k1o + 2 * k2o + 2 * k3o + k4o)], 1)
+
+    def f_torch_jac(x, u):
+        with torch.enable_grad():   # the MPC evaluates dynamics under no_grad
+            xr, ur = x.detach().requires_grad_(True), u.detach().requires_grad_(True)
+            xn = f_torch(xr, ur)
+            rows = [torch.autograd.grad(xn[:, i].sum(), (xr, ur), retain_graph=True) for i in range(2)]
+        A = torch.stack([r[0] for r in rows], 1)
+        Bm = torch.stack([r[1] for r in rows], 1)
+        return xn.detach(), (A, Bm)
+
+    res = {}
+    for name, dx, dxj in (("hip", None, None), ("torch", f_torch, f_torch_jac)):
+        if name == "hip":
+            prov = Pendulum1lDynamics(dt=h)
+            dx, dxj = prov, prov.jac
+        mpc = MPC(2, 1, T, u_lower=-2.0, u_upper=2.0, n_batch=B, dtype=dt)
+        mpc.reinitialize(x0, None)
+        mpc.al_iter = 2
+        cost = QuadCost(torch.diag_embed(Qd), q, torch.zeros(B, T, dtype=dt, device=dev))
+        x, u, _ = mpc(x0, cost, dx, dxj)
+        res[name] = (x.cpu(), u.cpu(), list(mpc.last_newton_per_al))
+    assert res["hip"][2] == res["torch"][2]
+    assert torch.allclose(res["hip"][0], res["torch"][0], atol=1e-6)
+    assert torch.allclose(res["hip"][1], res["torch"][1], atol=1e-6)
