@@ -261,7 +261,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     for (int i = 0; i < 10; ++i) qd.tacc[i] = 0;
 #endif
     QSTAMP(-1);
-    if (!(a.flags & ALQP_WS_PRIMED)) qd.stage_in((a.flags & ALQP_INIT_MERIT) || a.max_newton == 0 || a.al_iter == 0);
+    // the residual pre-pass is only needed when no forward sweep will run before r is used
+    if (!(a.flags & ALQP_WS_PRIMED)) qd.stage_in(a.max_newton == 0 || a.al_iter == 0);
 
     int step_id = 0;
     bool pend = false;  // a chosen step not yet applied (the next forward sweep applies it)
@@ -269,13 +270,19 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     int bad = 0;
     real rn2 = 0, phi_next = 0;
     for (int it = 0; it < a.al_iter; ++it) {
+        // starting merit of the iteration (al_utils.py:481): iterations > 0 get it from iter_end() of
+        // the previous one; the first gets it from its first forward sweep, or from a pass of its
+        // own when the launch has no Newton step
+        bool phi_from_forward = false;
         if (a.flags & ALQP_INIT_MERIT) {
-            if (it == 0) {
+            if (it > 0) {
+                phi_prev = phi_next;
+            } else if (a.max_newton > 0) {
+                phi_from_forward = true;
+            } else {
                 real p1[1];
                 qd.template merit_candidates<1>(p1, true);
                 phi_prev = p1[0];
-            } else {
-                phi_prev = phi_next;  // evaluated by iter_end() of the previous iteration
             }
         }
         pend = false;
@@ -283,7 +290,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
             real *tg = nullptr;
             if constexpr (TRACE) tg = (tr.g && active) ? tr.g + ((size_t)step_id * a.B + b) * T * N : nullptr;
             QSTAMP(9);  // everything between Newton steps
-            qd.forward(tg, alpha_pend, pend);
+            qd.forward(tg, alpha_pend, pend, (phi_from_forward && st == 0) ? &phi_prev : nullptr);
             real ph[20];
             qd.template backward<FUSE_LS>(ph);
             QSTAMP(-1);

@@ -272,7 +272,11 @@ struct Quad {
     // With `pending`, the step alpha*d the previous line search chose (d is still in the
     // records) is applied on the fly: z_t is read, advanced, used and written back here, which
     // saves the separate pass (this sweep recomputes the equality residuals anyway).
-    __device__ __forceinline__ void forward(real *g_out, real alpha, bool pending) {
+    // With `phi0` the sweep also returns the merit at the z it linearises at (everything the
+    // merit needs is in registers here): the starting merit of an AL iteration costs no pass of
+    // its own and the launch needs no residual pre-pass.
+    __device__ __forceinline__ void forward(real *g_out, real alpha, bool pending, real *phi0) {
+        real mrep = 0, mdist = 0;  // merit terms every lane computes alike / per-lane parts (own rows)
         real S[ST], Sy[SW];
         real vprev[NX], Syrep[NX];
 #pragma unroll
@@ -295,6 +299,7 @@ struct Quad {
             for (int j = 0; j < NX; ++j) {
                 real r = z0[j] - xi[j];
                 vprev[j] = fma_(rho, r, li[j]);
+                mrep = fma_(fma_(real(0.5) * rho, r, li[j]), r, mrep);  // initial-state rows
                 Syrep[j] = 0;
                 if ((j & 3) == q && active) recp(T - 1)[C::oR + j] = r;
             }
@@ -364,12 +369,14 @@ struct Quad {
                     const bool ok = dyn && r < NX;
                     v[s] = ok ? fma_(rho, rr, lm[s]) : real(0);
                     if (ok && active) rp[C::oR + r] = rr;
+                    mdist += ok ? fma_(fma_(real(0.5) * rho, rr, lm[s]), rr, real(0)) : real(0);
                 }
                 // ---- gradient (replicated in the 4 lanes) and diagonal of H_tt
 #pragma unroll
                 for (int j = 0; j < N; ++j) {
                     real g = fma_(Qt[j], zt[j], qt[j]);
                     real d = Qt[j];
+                    mrep = fma_(fma_(real(0.5) * Qt[j], zt[j], qt[j]), zt[j], mrep);
                     if (j < NX) {
                         g += vprev[j];
                         d += rho;
@@ -378,7 +385,9 @@ struct Quad {
                         real vu = zt[j] - bu[ju], vl = -zt[j] + bl[ju];
                         real au = vu >= 0 ? real(1) : real(0), al = vl >= 0 ? real(1) : real(0);
                         d = fma_(rho, au + al, d);
-                        g += fma_(rho, fmax_(vu, real(0)), lu[ju]) - fma_(rho, fmax_(vl, real(0)), ll[ju]);
+                        const real cu = fmax_(vu, real(0)), cl = fmax_(vl, real(0));
+                        g += fma_(rho, cu, lu[ju]) - fma_(rho, cl, ll[ju]);
+                        mrep += fma_(lu[ju], vu, ll[ju] * vl) + real(0.5) * rho * fma_(cu, cu, cl * cl);
                     }
                     if (dyn) {
                         real p = 0;
@@ -496,6 +505,7 @@ struct Quad {
             }
             ALQP_STAMP(3);  // forward: stores drained
         }
+        if (phi0) *phi0 = mrep + qsum(mdist);
     }
 
     // ---- backward sweep ---------------------------------------------------------------
