@@ -262,7 +262,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
 #endif
     QSTAMP(-1);
     // the residual pre-pass is only needed when no forward sweep will run before r is used
-    if (!(a.flags & ALQP_WS_PRIMED)) qd.stage_in(a.max_newton == 0 || a.al_iter == 0);
+    if (!(a.flags & ALQP_WS_PRIMED)) qd.stage_in(a.max_newton == 0 || a.al_iter == 0 || (!C::PHI0_FWD && (a.flags & ALQP_INIT_MERIT)));
 
     int step_id = 0;
     bool pend = false;  // a chosen step not yet applied (the next forward sweep applies it)
@@ -277,7 +277,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
         if (a.flags & ALQP_INIT_MERIT) {
             if (it > 0) {
                 phi_prev = phi_next;
-            } else if (a.max_newton > 0) {
+            } else if (C::PHI0_FWD && a.max_newton > 0) {
                 phi_from_forward = true;
             } else {
                 real p1[1];

@@ -131,6 +131,9 @@ struct QCfg {
         return o;
     }
     static constexpr int LW = lbase(SH);
+    // fp32: the starting merit comes out of the first forward sweep; fp64 is short of registers
+    // (it would spill 0.7 KB more) and keeps the residual pre-pass + a merit pass
+    static constexpr bool PHI0_FWD = sizeof(real) == 4;
     __host__ __device__ static constexpr int p4(int x) { return (x + 3) & ~3; }
     // The record also carries the stage's slice of every small per-stage array (working copies
     // of z and lam, copies of diag Q, q, c and the bounds): in their own arrays these are 52-68
@@ -299,7 +302,7 @@ struct Quad {
             for (int j = 0; j < NX; ++j) {
                 real r = z0[j] - xi[j];
                 vprev[j] = fma_(rho, r, li[j]);
-                mrep = fma_(fma_(real(0.5) * rho, r, li[j]), r, mrep);  // initial-state rows
+                if constexpr (C::PHI0_FWD) mrep = fma_(fma_(real(0.5) * rho, r, li[j]), r, mrep);  // initial-state rows
                 Syrep[j] = 0;
                 if ((j & 3) == q && active) recp(T - 1)[C::oR + j] = r;
             }
@@ -369,14 +372,14 @@ struct Quad {
                     const bool ok = dyn && r < NX;
                     v[s] = ok ? fma_(rho, rr, lm[s]) : real(0);
                     if (ok && active) rp[C::oR + r] = rr;
-                    mdist += ok ? fma_(fma_(real(0.5) * rho, rr, lm[s]), rr, real(0)) : real(0);
+                    if constexpr (C::PHI0_FWD) mdist += ok ? fma_(fma_(real(0.5) * rho, rr, lm[s]), rr, real(0)) : real(0);
                 }
                 // ---- gradient (replicated in the 4 lanes) and diagonal of H_tt
 #pragma unroll
                 for (int j = 0; j < N; ++j) {
                     real g = fma_(Qt[j], zt[j], qt[j]);
                     real d = Qt[j];
-                    mrep = fma_(fma_(real(0.5) * Qt[j], zt[j], qt[j]), zt[j], mrep);
+                    if constexpr (C::PHI0_FWD) mrep = fma_(fma_(real(0.5) * Qt[j], zt[j], qt[j]), zt[j], mrep);
                     if (j < NX) {
                         g += vprev[j];
                         d += rho;
@@ -387,7 +390,7 @@ struct Quad {
                         d = fma_(rho, au + al, d);
                         const real cu = fmax_(vu, real(0)), cl = fmax_(vl, real(0));
                         g += fma_(rho, cu, lu[ju]) - fma_(rho, cl, ll[ju]);
-                        mrep += fma_(lu[ju], vu, ll[ju] * vl) + real(0.5) * rho * fma_(cu, cu, cl * cl);
+                        if constexpr (C::PHI0_FWD) mrep += fma_(lu[ju], vu, ll[ju] * vl) + real(0.5) * rho * fma_(cu, cu, cl * cl);
                     }
                     if (dyn) {
                         real p = 0;
@@ -505,7 +508,7 @@ struct Quad {
             }
             ALQP_STAMP(3);  // forward: stores drained
         }
-        if (phi0) *phi0 = mrep + qsum(mdist);
+        if constexpr (C::PHI0_FWD) { if (phi0) *phi0 = mrep + qsum(mdist); }
     }
 
     // ---- backward sweep ---------------------------------------------------------------
@@ -945,37 +948,6 @@ struct Quad {
         bad = qor(bad);
     }
 
-    __device__ __forceinline__ void apply_step(real alpha) {
-        if (!active) return;
-#pragma unroll 4
-        for (int t = 0; t < T; ++t) {  // 4 stages of loads in flight per round trip
-            real *rp = recp(t);
-            real zz[SY], dd[SY], rr[SW], ss[SW];
-#pragma unroll
-            for (int m = 0; m < SY; ++m) {
-                const int j = 4 * m + q, jc = j < N ? j : N - 1;
-                zz[m] = rp[C::oZ + jc];
-                dd[m] = rp[C::oY + jc];
-            }
-#pragma unroll
-            for (int s = 0; s < SW; ++s) {
-                const int r = 4 * s + q, rc = r < NX ? r : NX - 1;
-                rr[s] = rp[C::oR + rc];
-                ss[s] = rp[C::oS + rc];
-            }
-#pragma unroll
-            for (int m = 0; m < SY; ++m) {
-                const int j = 4 * m + q;
-                if (j < N) rp[C::oZ + j] = fma_(alpha, dd[m], zz[m]);
-            }
-#pragma unroll
-            for (int s = 0; s < SW; ++s) {
-                const int r = 4 * s + q;
-                if (r < NX) rp[C::oR + r] = fma_(alpha, ss[s], rr[s]);
-            }
-        }
-    }
-
     __device__ __forceinline__ real rplus2(int &bad) {
         real acc = 0;
         for (int t = 0; t < T; ++t) {
@@ -1000,31 +972,6 @@ struct Quad {
         }
         bad = qor(bad);
         return qsum(acc);
-    }
-
-    // lam <- lam + rho r ; lam_ineq <- max(0, .)   (AL_mpc.py:316-317)
-    __device__ __forceinline__ void dual_update() {
-        if (!active) return;
-        for (int t = 0; t < T; ++t) {
-            real *rp = recp(t);
-#pragma unroll
-            for (int s = 0; s < SW; ++s) {
-                const int r = 4 * s + q;
-                if (r < NX) rp[C::oLE + r] = fma_(rho, rp[C::oR + r], rp[C::oLE + r]);
-            }
-#pragma unroll
-            for (int m = 0; m < SY; ++m) {
-                const int j = 4 * m + q;
-                if (j >= NX && j < N) {
-                    const int ju = j - NX;
-                    real u = rp[C::oZ + j];
-                    real a = fma_(rho, u - rp[C::oBU + ju], rp[C::oLU + ju]);
-                    real c = fma_(rho, rp[C::oBL + ju] - u, rp[C::oLU + NU + ju]);
-                    rp[C::oLU + ju] = a < 0 ? real(0) : a;
-                    rp[C::oLU + NU + ju] = c < 0 ? real(0) : c;
-                }
-            }
-        }
     }
 };
 
