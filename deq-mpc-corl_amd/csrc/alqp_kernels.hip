@@ -916,6 +916,109 @@ int dyn_pendulum1l_impl(long K, const void *x, const void *u, double h, const vo
     return hipGetLastError() == hipSuccess ? 0 : ALQP_E_LAUNCH;
 }
 
+// ---- dynamics provider: cartpole1l (deqmpc/my_envs/cartpole1l/src/generated_dynamics.c,
+//      generated_derivatives.c). RK4 of M(th) q'' = tau - (sin th th'^2, 0) + (0, 9.81 sin th),
+//      M = [[11, -cos th], [-cos th, 2]], with the six tangents w.r.t. (q, qdot, tau).
+template <typename real>
+struct Dual6 {
+    real v, d[6];
+};
+template <typename real>
+__device__ __forceinline__ Dual6<real> d6c(real v) {
+    Dual6<real> r;
+    r.v = v;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) r.d[i] = 0;
+    return r;
+}
+template <typename real>
+__device__ __forceinline__ Dual6<real> d6axpy(Dual6<real> a, real s, Dual6<real> b) {  // a + s b
+    Dual6<real> r;
+    r.v = fma_(s, b.v, a.v);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) r.d[i] = fma_(s, b.d[i], a.d[i]);
+    return r;
+}
+template <typename real>
+__device__ __forceinline__ Dual6<real> d6mul(Dual6<real> a, Dual6<real> b) {
+    Dual6<real> r;
+    r.v = a.v * b.v;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) r.d[i] = fma_(a.d[i], b.v, a.v * b.d[i]);
+    return r;
+}
+template <typename real>
+__device__ __forceinline__ void cart_acc(Dual6<real> th, Dual6<real> thd, Dual6<real> t0, Dual6<real> t1,
+                                         Dual6<real> &xdd, Dual6<real> &thdd) {
+    using D = Dual6<real>;
+    const real snv = sin(th.v), csv = cos(th.v);
+    D sn, cs;
+    sn.v = snv;
+    cs.v = csv;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        sn.d[i] = csv * th.d[i];
+        cs.d[i] = -snv * th.d[i];
+    }
+    const D r0 = d6axpy(t0, real(-1), d6mul(sn, d6mul(thd, thd)));  // tau0 - sin(th) thd^2
+    const D r1 = d6axpy(t1, real(9.81), sn);                         // tau1 + 9.81 sin(th)
+    const D det = d6axpy(d6c<real>(real(22)), real(-1), d6mul(cs, cs));
+    D idet;
+    idet.v = real(1) / det.v;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) idet.d[i] = -det.d[i] * idet.v * idet.v;
+    xdd = d6mul(idet, d6axpy(d6mul(cs, r1), real(2), r0));    // M^-1 = [[2, c], [c, 11]] / det
+    thdd = d6mul(idet, d6axpy(d6mul(cs, r0), real(11), r1));
+}
+template <typename real>
+__global__ __launch_bounds__(256) void k_dyn_cartpole1l(long K, const real *x, const real *tau, real h, const real *hpt,
+                                                        real *xn, real *J) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= K) return;
+    if (hpt) h = hpt[i];
+    using D = Dual6<real>;
+    real x0, x1, x2, x3;
+    gld4(x + 4 * i, x0, x1, x2, x3);
+    D px = d6c(x0), th = d6c(x1), xd = d6c(x2), thd = d6c(x3);
+    D t0 = d6c(tau[2 * i]), t1 = d6c(tau[2 * i + 1]);
+    px.d[0] = 1; th.d[1] = 1; xd.d[2] = 1; thd.d[3] = 1; t0.d[4] = 1; t1.d[5] = 1;
+    const real hh = real(0.5) * h, two = real(2), h6 = h / real(6);
+    D k1xd, k1td, k2xd, k2td, k3xd, k3td, k4xd, k4td;
+    cart_acc(th, thd, t0, t1, k1xd, k1td);
+    const D k2x = d6axpy(xd, hh, k1xd), k2t = d6axpy(thd, hh, k1td);
+    cart_acc(d6axpy(th, hh, thd), k2t, t0, t1, k2xd, k2td);
+    const D k3x = d6axpy(xd, hh, k2xd), k3t = d6axpy(thd, hh, k2td);
+    cart_acc(d6axpy(th, hh, k2t), k3t, t0, t1, k3xd, k3td);
+    const D k4x = d6axpy(xd, h, k3xd), k4t = d6axpy(thd, h, k3td);
+    cart_acc(d6axpy(th, h, k3t), k4t, t0, t1, k4xd, k4td);
+    D o[4];
+    o[0] = d6axpy(px, h6, d6axpy(d6axpy(xd, two, k2x), real(1), d6axpy(k4x, two, k3x)));
+    o[1] = d6axpy(th, h6, d6axpy(d6axpy(thd, two, k2t), real(1), d6axpy(k4t, two, k3t)));
+    o[2] = d6axpy(xd, h6, d6axpy(d6axpy(k1xd, two, k2xd), real(1), d6axpy(k4xd, two, k3xd)));
+    o[3] = d6axpy(thd, h6, d6axpy(d6axpy(k1td, two, k2td), real(1), d6axpy(k4td, two, k3td)));
+    // 16-byte stores: a lane's 4 + 24 outputs are contiguous
+    if (xn) gst4(xn + 4 * i, o[0].v, o[1].v, o[2].v, o[3].v);
+    if (J) {
+        real *jp = J + 24 * i;
+        real f[24];
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int c = 0; c < 6; ++c) f[6 * r + c] = o[r].d[c];
+#pragma unroll
+        for (int g = 0; g < 6; ++g) gst4(jp + 4 * g, f[4 * g], f[4 * g + 1], f[4 * g + 2], f[4 * g + 3]);
+    }
+}
+
+template <typename real>
+int dyn_cartpole1l_impl(long K, const void *x, const void *tau, double h, const void *hpt, void *xn, void *J, void *stream) {
+    if (K < 0 || !x || !tau || (!xn && !J)) return ALQP_E_BADARG;
+    if (K == 0) return 0;
+    hipLaunchKernelGGL(k_dyn_cartpole1l<real>, dim3((unsigned)((K + 255) / 256)), dim3(256), 0, (hipStream_t)stream, K,
+                       (const real *)x, (const real *)tau, (real)h, (const real *)hpt, (real *)xn, (real *)J);
+    return hipGetLastError() == hipSuccess ? 0 : ALQP_E_LAUNCH;
+}
+
 // batch-global exit test of the Newton loop, taken on the device (al_utils.py:551-564)
 __global__ void k_exit_test(const double *sumsq, double *ctl, int mode, double tol) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
@@ -946,6 +1049,13 @@ int alqp_dyn_pendulum1l_f32(long K, const void *x, const void *u, double h, cons
 }
 int alqp_dyn_pendulum1l_f64(long K, const void *x, const void *u, double h, const void *h_pt, void *xnext, void *F, void *stream) {
     return alqp::dyn_pendulum1l_impl<double>(K, x, u, h, h_pt, xnext, F, stream);
+}
+
+int alqp_dyn_cartpole1l_f32(long K, const void *x, const void *tau, double h, const void *h_pt, void *xnext, void *J, void *stream) {
+    return alqp::dyn_cartpole1l_impl<float>(K, x, tau, h, h_pt, xnext, J, stream);
+}
+int alqp_dyn_cartpole1l_f64(long K, const void *x, const void *tau, double h, const void *h_pt, void *xnext, void *J, void *stream) {
+    return alqp::dyn_cartpole1l_impl<double>(K, x, tau, h, h_pt, xnext, J, stream);
 }
 
 int alqp_exit_test(const double *sumsq, double *ctl, int mode, double tol, void *stream) {

@@ -49,3 +49,48 @@ class pendulum1l:
         _, F = be.dyn_pendulum1l(torch.cat((q_in, qdot_in), 1).contiguous(), tau_in.contiguous(), h_in, want_jac=True)
         # (dq'/dq, dq'/dqdot, dq'/dtau, dqdot'/dq, dqdot'/dqdot, dqdot'/dtau), each [bsz, 1, 1]
         return [F[:, i, j].reshape(-1, 1, 1).contiguous() for i in (0, 1) for j in (0, 1, 2)]
+
+
+class Cartpole1lDynamics:
+    """One-link cartpole (my_envs/cartpole.py:27-38 `CartpoleDynamics(nx=4)`): x = (cart position,
+    pole angle, their rates), pole angle 0 = upright; the action drives the cart only
+    (my_envs/dynamics.py:54-56), so tau = (u, 0)."""
+    nx, nu = 4, 1
+
+    def __init__(self, dt=0.05, backend=None):
+        self.dt = float(dt)
+        self.backend = backend
+
+    def _be(self):
+        if self.backend is None:
+            self.backend = default_backend()
+        return self.backend
+
+    @staticmethod
+    def _tau(u):
+        return torch.cat((u, torch.zeros_like(u)), 1).contiguous()
+
+    def __call__(self, x, u):
+        xn, _ = self._be().dyn_cartpole1l(x.contiguous(), self._tau(u), self.dt, want_jac=False)
+        return xn
+
+    def jac(self, x, u):
+        xn, J = self._be().dyn_cartpole1l(x.contiguous(), self._tau(u), self.dt, want_jac=True)
+        return xn, (J[..., :4], J[..., 4:5])
+
+
+class cartpole1l:
+    """Module-shaped twin of the reference's compiled `cartpole1l` package (same conventions as
+    `pendulum1l` above; the six Jacobian blocks are [bsz, 2, 2])."""
+
+    @staticmethod
+    def dynamics(q_in, qdot_in, tau_in, h_in):
+        be = default_backend()
+        xn, _ = be.dyn_cartpole1l(torch.cat((q_in, qdot_in), 1).contiguous(), tau_in.contiguous(), h_in, want_jac=False)
+        return [xn[:, :2].contiguous(), xn[:, 2:].contiguous()]
+
+    @staticmethod
+    def derivatives(q_in, qdot_in, tau_in, h_in):
+        be = default_backend()
+        _, J = be.dyn_cartpole1l(torch.cat((q_in, qdot_in), 1).contiguous(), tau_in.contiguous(), h_in, want_jac=True)
+        return [J[:, 2 * i:2 * i + 2, 2 * j:2 * j + 2].contiguous() for i in (0, 1) for j in (0, 1, 2)]

@@ -219,6 +219,16 @@ int alqp_exit_test(const double *sumsq, double *ctl, int mode, double tol, void 
 int alqp_dyn_pendulum1l_f32(long K, const void *x, const void *u, double h, const void *h_pt, void *xnext, void *F, void *stream);
 int alqp_dyn_pendulum1l_f64(long K, const void *x, const void *u, double h, const void *h_pt, void *xnext, void *F, void *stream);
 
+/*
+ * Dynamics provider, cartpole1l (deqmpc/my_envs/cartpole1l/src/dynamics.cpp:13-47 and the two
+ * generated files): one RK4 step of  M(th) q'' = tau - (sin(th) th'^2, 0) + (0, 9.81 sin(th)),
+ * M = [[11, -cos th], [-cos th, 2]], q = (cart x, pole angle th; th = 0 upright), and its Jacobian.
+ *   in : x[K][4] = (q, qdot), tau[K][2], h or h_pt[K]
+ *   out: xnext[K][4] (nullable), J[K][4][6] = d xnext / d(q, qdot, tau) (nullable)
+ */
+int alqp_dyn_cartpole1l_f32(long K, const void *x, const void *tau, double h, const void *h_pt, void *xnext, void *J, void *stream);
+int alqp_dyn_cartpole1l_f64(long K, const void *x, const void *tau, double h, const void *h_pt, void *xnext, void *J, void *stream);
+
 int alqp_abi_version(void);
 
 #ifdef __cplusplus

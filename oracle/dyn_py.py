@@ -17,12 +17,13 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = os.path.join(_HERE, "libdyn_oracle.so")
 _REF = os.path.join(_HERE, "_ref", "libpendulum1l_casadi.so")
+_REF_CP = os.path.join(_HERE, "_ref", "libcartpole1l_casadi.so")
 
 
 def build():
     if not os.path.exists(_LIB) or os.path.getmtime(_LIB) < os.path.getmtime(os.path.join(_HERE, "dyn_oracle.c")):
         subprocess.check_call(["make", "-C", _HERE, "-B", "libdyn_oracle.so"], stdout=subprocess.DEVNULL)
-    if os.path.isdir("/root/reference/deqmpc/my_envs/pendulum1l/src") and not os.path.exists(_REF):
+    if os.path.isdir("/root/reference/deqmpc/my_envs/pendulum1l/src") and not (os.path.exists(_REF) and os.path.exists(_REF_CP)):
         subprocess.check_call(["make", "-C", _HERE, "ref"], stdout=subprocess.DEVNULL)
     return _LIB
 
@@ -72,3 +73,47 @@ def pendulum1l_ref(x, u, h):
         A[i] = [[o6[0].value, o6[1].value], [o6[3].value, o6[4].value]]
         B[i] = [[o6[2].value], [o6[5].value]]
     return xn, A, B
+
+
+def cartpole1l(x, tau, h):
+    """x [K,4] = (cart x, theta, xdot, thetadot), tau [K,2] -> xn [K,4], J [K,4,6] = d xn / d(q, qd, tau)."""
+    build()
+    lib = C.CDLL(_LIB)
+    x = np.ascontiguousarray(x, np.float64)
+    tau = np.ascontiguousarray(tau, np.float64)
+    K = x.shape[0]
+    xn, J = np.empty((K, 4)), np.empty((K, 4, 6))
+    P = lambda a: a.ctypes.data_as(C.c_void_p)
+    lib.dyn_cartpole1l.argtypes = [C.c_long, C.c_void_p, C.c_void_p, C.c_double, C.c_void_p, C.c_void_p]
+    lib.dyn_cartpole1l(K, P(x), P(tau), float(h), P(xn), P(J))
+    return xn, J
+
+
+def have_ref_cartpole():
+    return os.path.exists(_REF_CP)
+
+
+def cartpole1l_ref(x, tau, h):
+    """The same through the reference's generated code. Outputs of eval_forward_derivatives are six
+    2x2 blocks (dq'/dq, dq'/dqdot, dq'/dtau, dqdot'/dq, dqdot'/dqdot, dqdot'/dtau), each stored
+    COLUMN-major (CasADi dense), cf. cartpole1l/src/dynamics_cpu.cpp."""
+    lib = C.CDLL(_REF_CP)
+    x = np.ascontiguousarray(x, np.float64)
+    tau = np.ascontiguousarray(tau, np.float64)
+    K = x.shape[0]
+    xn, J = np.empty((K, 4)), np.empty((K, 4, 6))
+    dbl = C.c_double
+    iw = (C.c_longlong * 64)()
+    w = (dbl * 4096)()
+    for i in range(K):
+        ins = [(dbl * 2)(*x[i, :2]), (dbl * 2)(*x[i, 2:]), (dbl * 2)(*tau[i]), (dbl * 1)(h)]
+        arg = (C.POINTER(dbl) * 4)(*[C.cast(a, C.POINTER(dbl)) for a in ins])
+        o2 = [(dbl * 2)(), (dbl * 2)()]
+        lib.eval_forward_dynamics(arg, (C.POINTER(dbl) * 2)(*[C.cast(a, C.POINTER(dbl)) for a in o2]), iw, w, 0)
+        xn[i] = list(o2[0]) + list(o2[1])
+        o6 = [(dbl * 4)() for _ in range(6)]
+        lib.eval_forward_derivatives(arg, (C.POINTER(dbl) * 6)(*[C.cast(a, C.POINTER(dbl)) for a in o6]), iw, w, 0)
+        blk = [np.array(list(b)).reshape(2, 2, order="F") for b in o6]
+        J[i, :2, 0:2], J[i, :2, 2:4], J[i, :2, 4:6] = blk[0], blk[1], blk[2]
+        J[i, 2:, 0:2], J[i, 2:, 2:4], J[i, 2:, 4:6] = blk[3], blk[4], blk[5]
+    return xn, J

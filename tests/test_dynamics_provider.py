@@ -10,6 +10,7 @@ import torch
 from oracle import dyn_py
 
 GOLD = np.load(os.path.join(os.path.dirname(__file__), "golden", "dyn_pendulum1l.npz"))
+GOLDC = np.load(os.path.join(os.path.dirname(__file__), "golden", "dyn_cartpole1l.npz"))
 
 
 @pytest.mark.parametrize("tag", ["h05", "h01"])
@@ -138,3 +139,66 @@ def test_mpc_nonlinear_mode_with_the_hip_provider():
     assert res["hip"][2] == res["torch"][2]
     assert torch.allclose(res["hip"][0], res["torch"][0], atol=1e-6)
     assert torch.allclose(res["hip"][1], res["torch"][1], atol=1e-6)
+
+
+# ---- cartpole1l ------------------------------------------------------------------------------
+@pytest.mark.parametrize("tag", ["h05", "h01"])
+def test_cartpole_restatement_matches_reference_vectors(tag):
+    xn, J = dyn_py.cartpole1l(GOLDC["x"], GOLDC["tau"], float(GOLDC[tag + "_h"]))
+    assert np.abs(xn - GOLDC[tag + "_xn"]).max() < 5e-14
+    assert np.abs(J - GOLDC[tag + "_J"]).max() < 1e-14
+
+
+def test_cartpole_restatement_jacobian_is_the_derivative_of_the_step():
+    x, tau, h = GOLDC["x"][:64], GOLDC["tau"][:64], 0.05
+    _, J = dyn_py.cartpole1l(x, tau, h)
+    eps = 1e-6
+    for j in range(6):
+        dx, dt_ = np.zeros_like(x), np.zeros_like(tau)
+        if j < 4:
+            dx[:, j] = eps
+        else:
+            dt_[:, j - 4] = eps
+        num = (dyn_py.cartpole1l(x + dx, tau + dt_, h)[0] - dyn_py.cartpole1l(x - dx, tau - dt_, h)[0]) / (2 * eps)
+        assert np.abs(num - J[:, :, j]).max() < 2e-6
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype,tol", [(torch.float64, 5e-13), (torch.float32, 5e-5)])
+@pytest.mark.parametrize("tag", ["h05", "h01"])
+def test_hip_cartpole_matches_reference_vectors(dtype, tol, tag):
+    from deq_mpc_corl_amd.backend import default_backend
+    be = default_backend()
+    dev = "cuda:0"
+    x = torch.tensor(GOLDC["x"], dtype=dtype, device=dev)
+    tau = torch.tensor(GOLDC["tau"], dtype=dtype, device=dev)
+    xn, J = be.dyn_cartpole1l(x, tau, float(GOLDC[tag + "_h"]))
+    torch.cuda.synchronize()
+    scale = 1.0 + np.abs(GOLDC[tag + "_xn"])
+    assert (np.abs(xn.cpu().numpy() - GOLDC[tag + "_xn"]) / scale).max() < tol
+    assert np.abs(J.cpu().numpy() - GOLDC[tag + "_J"]).max() < tol
+
+
+@pytest.mark.gpu
+def test_hip_cartpole_class_and_package_twin():
+    from deq_mpc_corl_amd import Cartpole1lDynamics
+    from deq_mpc_corl_amd.dynamics import cartpole1l
+    dev, dt = "cuda:0", torch.float64
+    sel = GOLDC["tau"][:, 1] == 0          # the rows the environments can produce: tau = (u, 0)
+    x = torch.tensor(GOLDC["x"][sel], dtype=dt, device=dev)
+    u = torch.tensor(GOLDC["tau"][sel][:, :1], dtype=dt, device=dev)
+    dyn = Cartpole1lDynamics(dt=0.05)
+    xn, (A, B) = dyn.jac(x, u)
+    assert A.shape == (x.shape[0], 4, 4) and B.shape == (x.shape[0], 4, 1)
+    assert np.abs(xn.cpu().numpy() - GOLDC["h05_xn"][sel]).max() < 5e-13
+    assert np.abs(A.cpu().numpy() - GOLDC["h05_J"][sel][:, :, :4]).max() < 5e-13
+    assert np.abs(B.cpu().numpy() - GOLDC["h05_J"][sel][:, :, 4:5]).max() < 5e-13
+    assert torch.equal(dyn(x, u), xn)
+    xa = torch.tensor(GOLDC["x"], dtype=dt, device=dev)
+    ta = torch.tensor(GOLDC["tau"], dtype=dt, device=dev)
+    h = torch.full((xa.shape[0], 1), 0.05, dtype=dt, device=dev)
+    qn, qdn = cartpole1l.dynamics(xa[:, :2].contiguous(), xa[:, 2:].contiguous(), ta, h)
+    assert np.abs(torch.cat((qn, qdn), 1).cpu().numpy() - GOLDC["h05_xn"]).max() < 5e-13
+    blocks = cartpole1l.derivatives(xa[:, :2].contiguous(), xa[:, 2:].contiguous(), ta, h)
+    assert len(blocks) == 6 and all(b.shape == (xa.shape[0], 2, 2) for b in blocks)
+    assert np.abs(blocks[4].cpu().numpy() - GOLDC["h05_J"][:, 2:, 2:4]).max() < 5e-13   # dqdot'/dqdot

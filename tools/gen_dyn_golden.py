@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
-"""Golden vectors for the pendulum1l dynamics provider, produced by RUNNING the reference's
+"""Golden vectors for the pendulum1l and cartpole1l dynamics providers, produced by RUNNING the reference's
 CasADi-generated code (compiled from its own sources into oracle/_ref by `make -C oracle ref`).
-Writes tests/golden/dyn_pendulum1l.npz (inputs and expected outputs only - data, no source)."""
+Writes tests/golden/dyn_pendulum1l.npz and dyn_cartpole1l.npz (inputs and expected outputs only - data, no source)."""
 import os
 import sys
 
@@ -25,6 +25,22 @@ for name, h in (("h05", 0.05), ("h01", 0.01)):
     xn, A, B = dyn_py.pendulum1l_ref(x, u, h)
     out.update({f"{name}_h": np.float64(h), f"{name}_xn": xn, f"{name}_A": A, f"{name}_B": B})
 np.savez(os.path.join(ROOT, "tests", "golden", "dyn_pendulum1l.npz"), x=x, u=u, **out)
+# ---- cartpole1l
+assert dyn_py.have_ref_cartpole(), "oracle/_ref/libcartpole1l_casadi.so missing"
+Kc = 512
+xc = np.stack([rng.normal(0, 1, Kc), rng.uniform(-np.pi, np.pi, Kc), rng.normal(0, 2, Kc), rng.normal(0, 4, Kc)], 1)
+tc = np.stack([rng.normal(0, 8, Kc), np.zeros(Kc)], 1)      # the environments drive tau[0] only ...
+tc[Kc // 2:, 1] = rng.normal(0, 2, Kc - Kc // 2)             # ... the generated code takes both
+xc[:3] = [[0, 0, 0, 0], [0, np.pi, 0, 0], [0.5, 0.2, -1.0, 6.0]]
+tc[:3] = [[0, 0], [0, 0], [20.0, 0]]
+outc = {}
+for name, h in (("h05", 0.05), ("h01", 0.01)):
+    xn, J = dyn_py.cartpole1l_ref(xc, tc, h)
+    outc.update({f"{name}_h": np.float64(h), f"{name}_xn": xn, f"{name}_J": J})
+np.savez(os.path.join(ROOT, "tests", "golden", "dyn_cartpole1l.npz"), x=xc, tau=tc, **outc)
+xn3, J3 = dyn_py.cartpole1l(xc, tc, 0.05)
+print("cartpole1l restatement vs reference (h=0.05): max |dxn| %.2e, |dJ| %.2e" % (
+    np.abs(xn3 - outc["h05_xn"]).max(), np.abs(J3 - outc["h05_J"]).max()))
 xn2, A2, B2 = dyn_py.pendulum1l(x, u, 0.05)
 print("restatement vs reference (h=0.05): max |dxn| %.2e, |dA| %.2e, |dB| %.2e" % (
     np.abs(xn2 - out["h05_xn"]).max(), np.abs(A2 - out["h05_A"]).max(), np.abs(B2 - out["h05_B"]).max()))
