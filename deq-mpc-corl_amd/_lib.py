@@ -43,6 +43,8 @@ ERRORS = {-1: "bad argument", -2: "unsupported (nx, nu) or horizon does not fit 
 _P = C.c_void_p
 _SIGS = {
     # name: (restype, argtypes) ; the f32/f64 pairs share a signature
+    "alqp_solve_nonlin": (C.c_int, [C.POINTER(AlqpDims), C.POINTER(AlqpParams), C.c_int, C.c_double, _P, _P, _P, _P, _P,
+                                    C.c_long, C.c_long, _P, _P, _P, _P, _P, _P, _P, _P, C.c_size_t, _P]),
     "alqp_dyn_pendulum1l": (C.c_int, [C.c_long, _P, _P, C.c_double, _P, _P, _P, _P]),
     "alqp_dyn_cartpole1l": (C.c_int, [C.c_long, _P, _P, C.c_double, _P, _P, _P, _P]),
     "alqp_solve_lin": (C.c_int, [C.POINTER(AlqpDims), C.POINTER(AlqpParams), _P, _P, _P, _P, _P, _P, _P,
@@ -65,6 +67,7 @@ _PLAIN = {
     "alqp_qps_per_wave": (C.c_int, [C.POINTER(AlqpDims), C.c_int]),
     "alqp_workspace_bytes": (C.c_size_t, [C.POINTER(AlqpDims), C.c_int]),
     "alqp_exit_test": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_void_p]),
+    "alqp_workspace_bytes_nonlin": (C.c_size_t, [C.POINTER(AlqpDims), C.c_int]),
 }
 
 EXPORTED_SYMBOLS = sorted([f"{n}_{s}" for n in _SIGS for s in ("f32", "f64")] + list(_PLAIN))

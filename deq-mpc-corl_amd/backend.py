@@ -127,6 +127,32 @@ class HipBackend:
                 _ptr(ws, "workspace", dt, True), ws_bytes, _stream())
         _lib.check(rc, "alqp_solve_lin_" + sfx)
 
+    def solve_nonlin(self, dims, dyn_id, dyn_h, Qd, q, x0, ulo, uhi, sb_u, st_u, z, lam, rho, phi, rnorm2=None,
+                     info=None, status=None, al_iter=2, max_newton=4,
+                     flags=_lib.ALQP_INIT_MERIT | _lib.ALQP_DUAL_UPDATE, rho_scale=10.0):
+        """Nonlinear fused solve (alqp_solve_nonlin): the dynamics model `dyn_id` is inlined."""
+        B, T, nx, nu = dims
+        dt = z.dtype
+        sfx = _dt(z)
+        d = _lib.AlqpDims(B, T, nx, nu)
+        need = int(self.lib.alqp_workspace_bytes_nonlin(C.byref(d), int(dt == torch.float64)))
+        if need == 0:
+            raise RuntimeError("mi_alqp: nonlinear fused solve not available for these sizes")
+        key = ("nl", z.device, dt)
+        ws = self._ws.get(key)
+        if ws is None or ws.numel() * ws.element_size() < need:
+            ws = torch.empty(need // z.element_size() + 16, dtype=dt, device=z.device)
+            self._ws[key] = ws
+        p = _lib.AlqpParams(al_iter, max_newton, 20, flags, rho_scale, 2, None)
+        fn = getattr(self.lib, "alqp_solve_nonlin_" + sfx)
+        rc = fn(C.byref(d), C.byref(p), int(dyn_id), float(dyn_h), _ptr(Qd, "Qd", dt), _ptr(q, "q", dt), _ptr(x0, "x0", dt),
+                _ptr(ulo, "u_lower", dt), _ptr(uhi, "u_upper", dt), sb_u, st_u, _ptr(z, "z", dt), _ptr(lam, "lam", dt),
+                _ptr(rho, "rho", dt), _ptr(phi, "phi", dt), _ptr(rnorm2, "rnorm2", dt, True),
+                _ptr(info, "info", torch.int32, True), _ptr(status, "status", torch.uint8, True),
+                _ptr(ws, "workspace", dt), need, _stream())
+        _lib.check(rc, "alqp_solve_nonlin_" + sfx)
+        self.last_variant = "quad"
+
     def dyn_pendulum1l(self, x, u, h, want_jac=True):
         """pendulum1l provider (alqp_dyn_pendulum1l): x [K,2], u [K,1], h float or [K(,1)] tensor
         -> xnext [K,2], F [K,2,3] or None."""

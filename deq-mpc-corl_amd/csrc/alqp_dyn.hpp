@@ -1,0 +1,152 @@
+// alqp_dyn.hpp - dynamics models that can be inlined into the solver kernels (the nonlinear
+// fused solve, alqp_solve_nonlin): one RK4 step x+ = f(x, u) of the reference's generated
+// per-robot packages, evaluated with dual numbers so that the same code gives the value
+// (NT = 0: line-search candidates, true residuals) and the Jacobian (NT = n tangents).
+//   pendulum1l : deqmpc/my_envs/pendulum1l/src/generated_dynamics.c:55-140
+//   cartpole1l : deqmpc/my_envs/cartpole1l/src/generated_dynamics.c (model: DESIGN.md section 9)
+// The same models back the provider kernels (alqp_dyn_*), parity-tested against the compiled
+// reference code (tests/test_dynamics_provider.py).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "alqp_team.hpp"  // fma_
+
+namespace alqp {
+
+template <typename real, int NT>
+struct Dual {
+    real v;
+    real d[NT > 0 ? NT : 1];
+};
+template <typename real, int NT>
+__device__ __forceinline__ Dual<real, NT> dconst(real v) {
+    Dual<real, NT> r;
+    r.v = v;
+#pragma unroll
+    for (int i = 0; i < NT; ++i) r.d[i] = 0;
+    return r;
+}
+template <typename real, int NT>
+__device__ __forceinline__ Dual<real, NT> daxpy(Dual<real, NT> a, real s, Dual<real, NT> b) {  // a + s b
+    Dual<real, NT> r;
+    r.v = fma_(s, b.v, a.v);
+#pragma unroll
+    for (int i = 0; i < NT; ++i) r.d[i] = fma_(s, b.d[i], a.d[i]);
+    return r;
+}
+template <typename real, int NT>
+__device__ __forceinline__ Dual<real, NT> dmul(Dual<real, NT> a, Dual<real, NT> b) {
+    Dual<real, NT> r;
+    r.v = a.v * b.v;
+#pragma unroll
+    for (int i = 0; i < NT; ++i) r.d[i] = fma_(a.d[i], b.v, a.v * b.d[i]);
+    return r;
+}
+template <typename real, int NT>
+__device__ __forceinline__ void dsincos(Dual<real, NT> a, Dual<real, NT> &sn, Dual<real, NT> &cs) {
+    const real s = sin(a.v), c = cos(a.v);
+    sn.v = s;
+    cs.v = c;
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {
+        sn.d[i] = c * a.d[i];
+        cs.d[i] = -s * a.d[i];
+    }
+}
+
+// ---- pendulum1l: x = (theta, omega), u = tau; theta'' = 4 tau - 19.62 sin(theta) ----------------
+template <typename real>
+struct DynPendulum1l {
+    static constexpr int NX = 2, NU = 1, ID = 1;
+    template <int NT>
+    __device__ __forceinline__ static Dual<real, NT> acc(Dual<real, NT> th, Dual<real, NT> ta) {
+        Dual<real, NT> sn, cs;
+        dsincos(th, sn, cs);
+        return daxpy(daxpy(dconst<real, NT>(0), real(4), ta), real(-19.62), sn);
+    }
+    template <int NT>
+    __device__ __forceinline__ static void step(const Dual<real, NT> (&z)[3], real h, Dual<real, NT> (&xn)[2]) {
+        using D = Dual<real, NT>;
+        const D th = z[0], om = z[1], ta = z[2];
+        const real hh = real(0.5) * h, two = real(2), h6 = h / real(6);
+        const D k1o = acc(th, ta);
+        const D om2 = daxpy(om, hh, k1o), k2o = acc(daxpy(th, hh, om), ta);
+        const D om3 = daxpy(om, hh, k2o), k3o = acc(daxpy(th, hh, om2), ta);
+        const D om4 = daxpy(om, h, k3o), k4o = acc(daxpy(th, h, om3), ta);
+        xn[0] = daxpy(th, h6, daxpy(daxpy(om, two, om2), real(1), daxpy(om4, two, om3)));
+        xn[1] = daxpy(om, h6, daxpy(daxpy(k1o, two, k2o), real(1), daxpy(k4o, two, k3o)));
+    }
+};
+
+// ---- cartpole1l: x = (cart x, theta, xdot, thetadot), u = force on the cart (tau = (u, 0)) ----
+template <typename real>
+struct DynCartpole1l {
+    static constexpr int NX = 4, NU = 1, ID = 2;
+    template <int NT>
+    __device__ __forceinline__ static void acc(Dual<real, NT> th, Dual<real, NT> thd, Dual<real, NT> t0, Dual<real, NT> &xdd,
+                                               Dual<real, NT> &thdd) {
+        using D = Dual<real, NT>;
+        D sn, cs;
+        dsincos(th, sn, cs);
+        const D r0 = daxpy(t0, real(-1), dmul(sn, dmul(thd, thd)));  // tau0 - sin(th) thd^2
+        const D r1 = daxpy(dconst<real, NT>(0), real(9.81), sn);      // 9.81 sin(th)
+        const D det = daxpy(dconst<real, NT>(real(22)), real(-1), dmul(cs, cs));
+        D idet;
+        idet.v = real(1) / det.v;
+#pragma unroll
+        for (int i = 0; i < NT; ++i) idet.d[i] = -det.d[i] * idet.v * idet.v;
+        xdd = dmul(idet, daxpy(dmul(cs, r1), real(2), r0));    // M^-1 = [[2, c], [c, 11]] / det
+        thdd = dmul(idet, daxpy(dmul(cs, r0), real(11), r1));
+    }
+    template <int NT>
+    __device__ __forceinline__ static void step(const Dual<real, NT> (&z)[5], real h, Dual<real, NT> (&xn)[4]) {
+        using D = Dual<real, NT>;
+        const D px = z[0], th = z[1], xd = z[2], thd = z[3], t0 = z[4];
+        const real hh = real(0.5) * h, two = real(2), h6 = h / real(6);
+        D k1xd, k1td, k2xd, k2td, k3xd, k3td, k4xd, k4td;
+        acc(th, thd, t0, k1xd, k1td);
+        const D k2x = daxpy(xd, hh, k1xd), k2t = daxpy(thd, hh, k1td);
+        acc(daxpy(th, hh, thd), k2t, t0, k2xd, k2td);
+        const D k3x = daxpy(xd, hh, k2xd), k3t = daxpy(thd, hh, k2td);
+        acc(daxpy(th, hh, k2t), k3t, t0, k3xd, k3td);
+        const D k4x = daxpy(xd, h, k3xd), k4t = daxpy(thd, h, k3td);
+        acc(daxpy(th, h, k3t), k4t, t0, k4xd, k4td);
+        xn[0] = daxpy(px, h6, daxpy(daxpy(xd, two, k2x), real(1), daxpy(k4x, two, k3x)));
+        xn[1] = daxpy(th, h6, daxpy(daxpy(thd, two, k2t), real(1), daxpy(k4t, two, k3t)));
+        xn[2] = daxpy(xd, h6, daxpy(daxpy(k1xd, two, k2xd), real(1), daxpy(k4xd, two, k3xd)));
+        xn[3] = daxpy(thd, h6, daxpy(daxpy(k1td, two, k2td), real(1), daxpy(k4td, two, k3td)));
+    }
+};
+
+// value only: xn[NX] = f(z[0..N))
+template <typename Dyn, typename real>
+__device__ __forceinline__ void dyn_value(const real (&z)[Dyn::NX + Dyn::NU], real h, real (&xn)[Dyn::NX]) {
+    constexpr int N = Dyn::NX + Dyn::NU;
+    Dual<real, 0> zd[N], xd[Dyn::NX];
+#pragma unroll
+    for (int j = 0; j < N; ++j) zd[j].v = z[j];
+    Dyn::template step<0>(zd, h, xd);
+#pragma unroll
+    for (int i = 0; i < Dyn::NX; ++i) xn[i] = xd[i].v;
+}
+// value and Jacobian J[NX][N] = d f / d z
+template <typename Dyn, typename real>
+__device__ __forceinline__ void dyn_value_jac(const real (&z)[Dyn::NX + Dyn::NU], real h, real (&xn)[Dyn::NX],
+                                              real (&J)[Dyn::NX][Dyn::NX + Dyn::NU]) {
+    constexpr int N = Dyn::NX + Dyn::NU;
+    Dual<real, N> zd[N], xd[Dyn::NX];
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+        zd[j] = dconst<real, N>(z[j]);
+        zd[j].d[j] = 1;
+    }
+    Dyn::template step<N>(zd, h, xd);
+#pragma unroll
+    for (int i = 0; i < Dyn::NX; ++i) {
+        xn[i] = xd[i].v;
+#pragma unroll
+        for (int j = 0; j < N; ++j) J[i][j] = xd[i].d[j];
+    }
+}
+
+}  // namespace alqp

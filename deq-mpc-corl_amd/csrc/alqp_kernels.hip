@@ -35,6 +35,7 @@ struct SolveArgs {
     unsigned char *status;
     real *factor;
     const double *skip;  // nullable: *skip != 0 -> the launch does nothing (device-side loop exit)
+    real dyn_h;          // nonlinear fused solve: step length of the inlined dynamics model
 };
 
 template <typename real>
@@ -220,11 +221,16 @@ __device__ unsigned long long g_phase_cycles[10];
 #else
 #define QSTAMP(b)
 #endif
-template <typename real, int NX, int NU, bool TRACE>
+// Dyn = NoDyn: affine dynamics from the caller's F, c (alqp_solve_lin). Dyn = a model of alqp_dyn.hpp:
+// the nonlinear solve with that model inlined (alqp_solve_nonlin): every Newton step re-linearises
+// on the device, the line search and the dual update use the true dynamics; a.F then points at the
+// F region of the workspace (behind the records) and a.c is unused.
+template <typename real, int NX, int NU, bool TRACE, class Dyn = NoDyn>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_solve_lin_quad(SolveArgs<real> a, TraceArgs<real> tr, real *ws) {
     using C = QCfg<real, NX, NU>;
+    constexpr bool NL = Dyn::ID != 0;
     // fp64 is short of registers already: its line search keeps a pass of its own
-    constexpr bool FUSE_LS = ALQP_FUSE_LS && sizeof(real) == 4;
+    constexpr bool FUSE_LS = ALQP_FUSE_LS && sizeof(real) == 4 && !NL;
     constexpr int N = C::N;
     if (a.skip && *a.skip != 0.0) return;  // wave-uniform
     const int lane = threadIdx.x, qi = lane >> 2;
@@ -254,6 +260,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     qd.gz = a.z + (size_t)b * T * N;
     qd.glam = a.lam + (size_t)b * M;
     qd.rec = ws + (size_t)b * T * C::RECW;
+    qd.gFw = const_cast<real *>(qd.gF);
+    qd.dyn_h = a.dyn_h;
     qd.rho = a.rho[b];
     qd.info = 0;
     real phi_prev = a.phi[b];
@@ -262,7 +270,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
 #endif
     QSTAMP(-1);
     // the residual pre-pass is only needed when no forward sweep will run before r is used
-    if (!(a.flags & ALQP_WS_PRIMED)) qd.stage_in(a.max_newton == 0 || a.al_iter == 0 || (!C::PHI0_FWD && (a.flags & ALQP_INIT_MERIT)));
+    if (!(a.flags & ALQP_WS_PRIMED)) {
+        if constexpr (NL) qd.stage_in(false, false);
+        else qd.stage_in(a.max_newton == 0 || a.al_iter == 0 || (!C::PHI0_FWD && (a.flags & ALQP_INIT_MERIT)));
+    }
 
     int step_id = 0;
     bool pend = false;  // a chosen step not yet applied (the next forward sweep applies it)
@@ -280,6 +291,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
             } else if (C::PHI0_FWD && a.max_newton > 0) {
                 phi_from_forward = true;
             } else {
+                if constexpr (NL) qd.template linearize<Dyn>(real(0), false);  // true residuals for the merit
                 real p1[1];
                 qd.template merit_candidates<1>(p1, true);
                 phi_prev = p1[0];
@@ -290,6 +302,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
             real *tg = nullptr;
             if constexpr (TRACE) tg = (tr.g && active) ? tr.g + ((size_t)step_id * a.B + b) * T * N : nullptr;
             QSTAMP(9);  // everything between Newton steps
+            if constexpr (NL) {
+                qd.template linearize<Dyn>(alpha_pend, pend);
+                pend = false;
+            }
             qd.forward(tg, alpha_pend, pend, (phi_from_forward && st == 0) ? &phi_prev : nullptr);
             real ph[20];
             qd.template backward<FUSE_LS>(ph);
@@ -301,7 +317,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
                         for (int j = qd.q; j < N; j += 4) td[t * N + j] = qd.recp(t)[C::oY + j];
                 }
             }
-            if constexpr (!FUSE_LS) qd.template merit_candidates<20>(ph, false);
+            if constexpr (NL) qd.template merit_nonlin<Dyn>(ph);
+            else if constexpr (!FUSE_LS) qd.template merit_candidates<20>(ph, false);
             QSTAMP(6);  // line-search candidates
             int kbest = 0;
             real best = ph[0];
@@ -331,7 +348,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
             phi_prev = best;  // merit <- new_merit even when rejected (al_utils.py:569)
         }
         bad = 0;
-        qd.iter_end(alpha_pend, pend, (a.flags & ALQP_DUAL_UPDATE) != 0, (real)a.rho_scale, it + 1 == a.al_iter,
+        qd.template iter_end<Dyn>(alpha_pend, pend, (a.flags & ALQP_DUAL_UPDATE) != 0, (real)a.rho_scale, it + 1 == a.al_iter,
                     phi_next, rn2, bad);
         pend = false;
     }
@@ -642,6 +659,8 @@ int dispatch_solve_quad(int nx, int nu, const SolveArgs<real> &a, const TraceArg
                         hipStream_t stream);
 template <typename real>
 int dispatch_backward_quad(int nx, int nu, const BwdArgs<real> &a, real *ws, hipStream_t stream);
+template <typename real>
+int dispatch_solve_nonlin(int dyn_id, int nx, int nu, const SolveArgs<real> &a, real *ws, hipStream_t stream);
 
 #if ALQP_BUILD_QUAD
 template <typename real, int NX, int NU, typename Fn, typename... Args>
@@ -673,11 +692,25 @@ int dispatch_backward_quad(int nx, int nu, const BwdArgs<real> &a, real *ws, hip
     return ALQP_E_UNSUPPORTED;
 }
 
+// nonlinear fused solve: the models of alqp_dyn.hpp, each with its own (nx, nu)
+template <typename real>
+int dispatch_solve_nonlin(int dyn_id, int nx, int nu, const SolveArgs<real> &a, real *ws, hipStream_t stream) {
+    if (dyn_id == DynPendulum1l<real>::ID && nx == 2 && nu == 1)
+        return launch_quad_kernel<real, 2, 1>(k_solve_lin_quad<real, 2, 1, false, DynPendulum1l<real>>, a.B, stream, a,
+                                              TraceArgs<real>{}, ws);
+    if (dyn_id == DynCartpole1l<real>::ID && nx == 4 && nu == 1)
+        return launch_quad_kernel<real, 4, 1>(k_solve_lin_quad<real, 4, 1, false, DynCartpole1l<real>>, a.B, stream, a,
+                                              TraceArgs<real>{}, ws);
+    return ALQP_E_UNSUPPORTED;
+}
+
 #if ALQP_QUAD_F32
+template int dispatch_solve_nonlin<float>(int, int, int, const SolveArgs<float> &, float *, hipStream_t);
 template int dispatch_solve_quad<float>(int, int, const SolveArgs<float> &, const TraceArgs<float> *, float *, hipStream_t);
 template int dispatch_backward_quad<float>(int, int, const BwdArgs<float> &, float *, hipStream_t);
 #endif
 #if ALQP_QUAD_F64
+template int dispatch_solve_nonlin<double>(int, int, int, const SolveArgs<double> &, double *, hipStream_t);
 template int dispatch_solve_quad<double>(int, int, const SolveArgs<double> &, const TraceArgs<double> *, double *, hipStream_t);
 template int dispatch_backward_quad<double>(int, int, const BwdArgs<double> &, double *, hipStream_t);
 #endif
@@ -772,6 +805,40 @@ int solve_lin_impl(const AlqpDims *dims, const AlqpParams *prm, const void *Qd, 
     }
     if (variant != 1) return ALQP_E_BADARG;
     return dispatch_solve<real>(dims->nx, dims->nu, a, trace ? &tr : nullptr, (hipStream_t)stream);
+}
+
+// nonlinear fused solve: workspace = [records | F linearisations [B][T-1][nx][n]]
+template <typename real>
+size_t nonlin_ws_bytes(int nx, int nu, int B, int T) {
+    const size_t rec = quad_ws_bytes<real>(nx, nu, B, T);
+    if (rec == 0) return 0;
+    return rec + (size_t)B * (T - 1) * nx * (nx + nu) * sizeof(real);
+}
+
+template <typename real>
+int solve_nonlin_impl(const AlqpDims *dims, const AlqpParams *prm, int dyn_id, double dyn_h, const void *Qd, const void *q,
+                      const void *x0, const void *u_lo, const void *u_hi, long sb_u, long st_u, void *z, void *lam,
+                      void *rho, void *phi, void *rnorm2, int *info, unsigned char *status, void *workspace,
+                      size_t ws_bytes, void *stream) {
+    if (!dims_ok(dims) || !prm || !Qd || !q || !x0 || !u_lo || !u_hi || !z || !lam || !rho || !phi || !workspace)
+        return ALQP_E_BADARG;
+    if (prm->n_ls != 20 || prm->al_iter < 0 || prm->max_newton < 0) return ALQP_E_BADARG;
+    if (prm->flags & (ALQP_SAVE_FACTOR | ALQP_WS_PRIMED)) return ALQP_E_UNSUPPORTED;
+    const size_t need = nonlin_ws_bytes<real>(dims->nx, dims->nu, dims->B, dims->T);
+    if (need == 0) return ALQP_E_UNSUPPORTED;
+    if (ws_bytes < need) return ALQP_E_BADARG;
+    SolveArgs<real> a = {};
+    a.B = dims->B; a.T = dims->T;
+    a.al_iter = prm->al_iter; a.max_newton = prm->max_newton; a.n_ls = prm->n_ls; a.flags = prm->flags;
+    a.rho_scale = (real)prm->rho_scale;
+    a.Qd = (const real *)Qd; a.q = (const real *)q; a.c = nullptr; a.x0 = (const real *)x0;
+    a.F = (const real *)((const char *)workspace + quad_ws_bytes<real>(dims->nx, dims->nu, dims->B, dims->T));
+    a.ulo = (const real *)u_lo; a.uhi = (const real *)u_hi; a.sb_u = sb_u; a.st_u = st_u;
+    a.z = (real *)z; a.lam = (real *)lam; a.rho = (real *)rho; a.phi = (real *)phi;
+    a.rnorm2 = (real *)rnorm2; a.info = info; a.status = status; a.factor = nullptr;
+    a.skip = prm->skip_flag;
+    a.dyn_h = (real)dyn_h;
+    return dispatch_solve_nonlin<real>(dyn_id, dims->nx, dims->nu, a, (real *)workspace, (hipStream_t)stream);
 }
 
 template <typename real>
@@ -1056,6 +1123,26 @@ int alqp_dyn_cartpole1l_f32(long K, const void *x, const void *tau, double h, co
 }
 int alqp_dyn_cartpole1l_f64(long K, const void *x, const void *tau, double h, const void *h_pt, void *xnext, void *J, void *stream) {
     return alqp::dyn_cartpole1l_impl<double>(K, x, tau, h, h_pt, xnext, J, stream);
+}
+
+size_t alqp_workspace_bytes_nonlin(const AlqpDims *dims, int is_f64) {
+    if (!alqp::dims_ok(dims)) return 0;
+    return is_f64 ? alqp::nonlin_ws_bytes<double>(dims->nx, dims->nu, dims->B, dims->T)
+                  : alqp::nonlin_ws_bytes<float>(dims->nx, dims->nu, dims->B, dims->T);
+}
+int alqp_solve_nonlin_f32(const AlqpDims *dims, const AlqpParams *prm, int dyn_id, double dyn_h, const void *Qd,
+                          const void *q, const void *x0, const void *u_lo, const void *u_hi, long sb_u, long st_u, void *z,
+                          void *lam, void *rho, void *phi, void *rnorm2, int *info, unsigned char *status, void *workspace,
+                          size_t ws_bytes, void *stream) {
+    return alqp::solve_nonlin_impl<float>(dims, prm, dyn_id, dyn_h, Qd, q, x0, u_lo, u_hi, sb_u, st_u, z, lam, rho, phi,
+                                          rnorm2, info, status, workspace, ws_bytes, stream);
+}
+int alqp_solve_nonlin_f64(const AlqpDims *dims, const AlqpParams *prm, int dyn_id, double dyn_h, const void *Qd,
+                          const void *q, const void *x0, const void *u_lo, const void *u_hi, long sb_u, long st_u, void *z,
+                          void *lam, void *rho, void *phi, void *rnorm2, int *info, unsigned char *status, void *workspace,
+                          size_t ws_bytes, void *stream) {
+    return alqp::solve_nonlin_impl<double>(dims, prm, dyn_id, dyn_h, Qd, q, x0, u_lo, u_hi, sb_u, st_u, z, lam, rho, phi,
+                                           rnorm2, info, status, workspace, ws_bytes, stream);
 }
 
 int alqp_exit_test(const double *sumsq, double *ctl, int mode, double tol, void *stream) {

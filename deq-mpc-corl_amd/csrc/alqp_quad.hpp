@@ -27,6 +27,7 @@
 #include <hip/hip_runtime.h>
 
 #include "alqp_team.hpp"  // fma_, rsqrt_, fmax_, fabs_, pad4
+#include "alqp_dyn.hpp"   // inlinable dynamics models (nonlinear fused solve)
 
 namespace alqp {
 
@@ -111,6 +112,11 @@ __device__ inline void gload(const real *p, real (&dst)[LEN]) {
     for (int c = (LEN / 4) * 4; c < LEN; ++c) dst[c] = p[c];
 }
 
+// "no dynamics model": the affine (LinDx) solve reads F and c from the caller's arrays
+struct NoDyn {
+    static constexpr int ID = 0;
+};
+
 template <typename real, int NX_, int NU_>
 struct QCfg {
     static constexpr int NX = NX_, NU = NU_, N = NX_ + NU_;
@@ -168,6 +174,8 @@ struct Quad {
     real *gz, *glam, *rec;
     real rho;
     int info;
+    real *gFw;   // nonlinear fused solve: this instance's F_t linearisations (inside the workspace; gF points here too)
+    real dyn_h;  //   step length of the dynamics model
 
     __device__ __forceinline__ real uhi(int t, int j) const { return guhi[t * st_u + j]; }
     __device__ __forceinline__ real ulo(int t, int j) const { return gulo[t * st_u + j]; }
@@ -226,7 +234,7 @@ struct Quad {
     // Kernel start: the stage's slice of z, lam, diag Q, q, c and the bounds -> its record, and
     // (when the launch starts with a merit evaluation or is a dual update only) the equality
     // residuals at the current z; a forward sweep recomputes them anyway.
-    __device__ __forceinline__ void stage_in(bool with_residual) {
+    __device__ __forceinline__ void stage_in(bool with_residual, bool have_c = true) {
 #pragma unroll 2
         for (int t = 0; t < T; ++t) {
             const bool dyn = t < T - 1;
@@ -239,7 +247,7 @@ struct Quad {
                 copy_slice<2 * NU>(glam + T * NX + t * 2 * NU, rp + C::oLU);
                 copy_slice<NU>(guhi + t * st_u, rp + C::oBU);
                 copy_slice<NU>(gulo + t * st_u, rp + C::oBL);
-                if (dyn) copy_slice<NX>(gc + t * NX, rp + C::oC);
+                if (dyn && have_c) copy_slice<NX>(gc + t * NX, rp + C::oC);
             }
             if (with_residual) {
                 real W[SW][N], zt[N];
@@ -269,6 +277,138 @@ struct Quad {
             copy_slice<NX>(rp + C::oLE, glam + t * NX);
             copy_slice<2 * NU>(rp + C::oLU, glam + T * NX + t * 2 * NU);
         }
+    }
+
+    // ---- nonlinear fused solve (a dynamics model Dyn is inlined, alqp_dyn.hpp) -----------------
+    // Linearisation pass of a Newton step (al_utils.py:233-248, dx_jac at the current iterate):
+    // applies the pending line-search step, then per stage x+ = f(z_t) and J = df/dz by dual
+    // numbers (every lane of the quad evaluates the model: it is tiny next to the factorisation),
+    // F_t = J -> the workspace, c_t = f(z_t) - J z_t and r_t = x_{t+1} - f(z_t) -> the record. The
+    // sweeps then run unchanged on (F_t, c_t).
+    template <class Dyn>
+    __device__ __forceinline__ void linearize(real alpha, bool pend) {
+        static_assert(Dyn::NX == NX && Dyn::NU == NU, "model / kernel size mismatch");
+        for (int t = 0; t < T; ++t) {
+            const bool dyn = t < T - 1;
+            real *rp = recp(t);
+            const real *rn = recp(dyn ? t + 1 : t);
+            real zt[N], dt[N], zn[SW], dn[SW];
+            gload<N>(rp + C::oZ, zt);
+            gload<N>(rp + C::oY, dt);
+#pragma unroll
+            for (int s = 0; s < SW; ++s) {
+                const int rc = (4 * s + q < NX) ? 4 * s + q : NX - 1;
+                zn[s] = rn[C::oZ + rc];
+                dn[s] = rn[C::oY + rc];
+            }
+            if (pend) {
+#pragma unroll
+                for (int k = 0; k < N; ++k) zt[k] = fma_(alpha, dt[k], zt[k]);
+#pragma unroll
+                for (int s = 0; s < SW; ++s) zn[s] = fma_(alpha, dn[s], zn[s]);
+                if (active) {
+#pragma unroll
+                    for (int m = 0; m < SY; ++m) {
+                        const real zv = sel4(zt[4 * m], (4 * m + 1 < N) ? zt[(4 * m + 1 < N) ? 4 * m + 1 : 0] : real(0),
+                                             (4 * m + 2 < N) ? zt[(4 * m + 2 < N) ? 4 * m + 2 : 0] : real(0),
+                                             (4 * m + 3 < N) ? zt[(4 * m + 3 < N) ? 4 * m + 3 : 0] : real(0), q);
+                        if (4 * m + 3 < N || 4 * m + q < N) rp[C::oZ + 4 * m + q] = zv;
+                    }
+                }
+            }
+            if (dyn) {
+                real xn[NX], J[NX][N];
+                dyn_value_jac<Dyn, real>(zt, dyn_h, xn, J);
+#pragma unroll
+                for (int s = 0; s < SW; ++s) {
+                    const int r = 4 * s + q;
+                    real Jr[N];
+#pragma unroll
+                    for (int k = 0; k < N; ++k)
+                        Jr[k] = sel4(J[4 * s][k], (4 * s + 1 < NX) ? J[(4 * s + 1 < NX) ? 4 * s + 1 : 0][k] : real(0),
+                                     (4 * s + 2 < NX) ? J[(4 * s + 2 < NX) ? 4 * s + 2 : 0][k] : real(0),
+                                     (4 * s + 3 < NX) ? J[(4 * s + 3 < NX) ? 4 * s + 3 : 0][k] : real(0), q);
+                    const real xr = sel4(xn[4 * s], (4 * s + 1 < NX) ? xn[(4 * s + 1 < NX) ? 4 * s + 1 : 0] : real(0),
+                                         (4 * s + 2 < NX) ? xn[(4 * s + 2 < NX) ? 4 * s + 2 : 0] : real(0),
+                                         (4 * s + 3 < NX) ? xn[(4 * s + 3 < NX) ? 4 * s + 3 : 0] : real(0), q);
+                    real c = xr;
+#pragma unroll
+                    for (int k = 0; k < N; ++k) c = fma_(-Jr[k], zt[k], c);
+                    if ((4 * s + 3 < NX || r < NX) && active) {
+                        real *Fr = gFw + ((size_t)t * NX + r) * N;
+#pragma unroll
+                        for (int k = 0; k < N; ++k) Fr[k] = Jr[k];
+                        rp[C::oC + r] = c;
+                        rp[C::oR + r] = zn[s] - xr;
+                    }
+                }
+            }
+        }
+    }
+    // Merit of the 20 line-search candidates with the TRUE dynamics (al_utils.py:618-633): lane q of
+    // the quad evaluates candidates k = 4i + q (i = 0..4) completely, then the values are exchanged.
+    template <class Dyn>
+    __device__ __forceinline__ void merit_nonlin(real (&phi)[20]) {
+        real m[5];
+#pragma unroll
+        for (int i = 0; i < 5; ++i) m[i] = 0;
+        real x0v[NX], li[NX];
+        gload<NX>(gx0, x0v);
+        gload<NX>(recp(T - 1) + C::oLE, li);
+        const real a0 = sel4(real(1), real(0.5), real(0.25), real(0.125), q);
+        for (int t = 0; t < T; ++t) {
+            const bool dyn = t < T - 1;
+            const real *rp = recp(t), *rn = recp(dyn ? t + 1 : t);
+            real zt[N], dt[N], Qt[N], qt[N], zn[NX], dn[NX], le[NX], lu[NU], ll[NU], bu[NU], bl[NU];
+            gload<N>(rp + C::oZ, zt);
+            gload<N>(rp + C::oY, dt);
+            gload<N>(rp + C::oQ, Qt);
+            gload<N>(rp + C::oq, qt);
+            gload<NX>(rn + C::oZ, zn);
+            gload<NX>(rn + C::oY, dn);
+            gload<NX>(rp + C::oLE, le);
+            gload<NU>(rp + C::oLU, lu);
+            gload<NU>(rp + C::oLU + NU, ll);
+            gload<NU>(rp + C::oBU, bu);
+            gload<NU>(rp + C::oBL, bl);
+            real alpha = a0;
+#pragma unroll
+            for (int i = 0; i < 5; ++i) {
+                real zc[N];
+                real acc = 0;
+#pragma unroll
+                for (int j = 0; j < N; ++j) {
+                    zc[j] = fma_(alpha, dt[j], zt[j]);
+                    acc = fma_(fma_(real(0.5) * Qt[j], zc[j], qt[j]), zc[j], acc);
+                }
+#pragma unroll
+                for (int ju = 0; ju < NU; ++ju) {
+                    const real vu = zc[NX + ju] - bu[ju], vl = bl[ju] - zc[NX + ju];
+                    const real cu = fmax_(vu, real(0)), cl = fmax_(vl, real(0));
+                    acc += fma_(lu[ju], vu, ll[ju] * vl) + real(0.5) * rho * fma_(cu, cu, cl * cl);
+                }
+                if (dyn) {
+                    real xn[NX];
+                    dyn_value<Dyn, real>(zc, dyn_h, xn);
+#pragma unroll
+                    for (int r = 0; r < NX; ++r) {
+                        const real rr = fma_(alpha, dn[r], zn[r]) - xn[r];
+                        acc = fma_(fma_(real(0.5) * rho, rr, le[r]), rr, acc);
+                    }
+                }
+                if (t == 0) {
+#pragma unroll
+                    for (int r = 0; r < NX; ++r) {
+                        const real rr = zc[r] - x0v[r];
+                        acc = fma_(fma_(real(0.5) * rho, rr, li[r]), rr, acc);
+                    }
+                }
+                m[i] += acc;
+                alpha *= real(0.0625);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 20; ++k) phi[k] = qbv(m[k >> 2], k);
     }
 
     // ---- forward sweep: gradient, factorisation, forward substitution ------------------
@@ -851,6 +991,9 @@ struct Quad {
     // next iteration's starting merit (same expression order as merit_candidates<1>(., true)),
     // ||r_+||^2 and the finiteness flag (al_utils.py:545-549); on the last iteration also the
     // copy-out of z and lam.
+    // With a dynamics model (Dyn::ID != 0) the residuals are re-evaluated with the TRUE dynamics at
+    // the new z (AL_mpc.py:315: the dual update never uses the linearisation).
+    template <class Dyn = NoDyn>
     __device__ __forceinline__ void iter_end(real alpha, bool pend, bool dual, real rho_scale, bool write_out,
                                              real &phi_next, real &rn2, int &bad) {
         constexpr int MU0 = NX / 4;
@@ -884,6 +1027,33 @@ struct Quad {
                 rv[s] = rp[C::oR + rc];
                 sv[s] = rp[C::oS + rc];
                 lv[s] = rp[C::oLE + rc];
+            }
+            real rtrue[SW];
+#pragma unroll
+            for (int s = 0; s < SW; ++s) rtrue[s] = 0;
+            if constexpr (Dyn::ID != 0) {
+                if (t < T - 1) {
+                    const real *rn_ = recp(t + 1);
+                    real zr[N], dr[N], xn[NX];
+                    gload<N>(rp + C::oZ, zr);
+                    gload<N>(rp + C::oY, dr);
+                    if (pend) {
+#pragma unroll
+                        for (int k = 0; k < N; ++k) zr[k] = fma_(alpha, dr[k], zr[k]);
+                    }
+                    dyn_value<Dyn, real>(zr, dyn_h, xn);
+#pragma unroll
+                    for (int s = 0; s < SW; ++s) {
+                        const int rc = (4 * s + q < NX) ? 4 * s + q : NX - 1;
+                        real znn = rn_[C::oZ + rc];
+                        const real dnn = rn_[C::oY + rc];
+                        if (pend) znn = fma_(alpha, dnn, znn);
+                        const real xr = sel4(xn[4 * s], (4 * s + 1 < NX) ? xn[(4 * s + 1 < NX) ? 4 * s + 1 : 0] : real(0),
+                                             (4 * s + 2 < NX) ? xn[(4 * s + 2 < NX) ? 4 * s + 2 : 0] : real(0),
+                                             (4 * s + 3 < NX) ? xn[(4 * s + 3 < NX) ? 4 * s + 3 : 0] : real(0), q);
+                        rtrue[s] = znn - xr;
+                    }
+                }
             }
 #pragma unroll
             for (int m = 0; m < SY; ++m) {
@@ -929,10 +1099,13 @@ struct Quad {
                 const int r = 4 * s + q;
                 const bool valid = 4 * s + 3 < NX || r < NX;
                 const real ok = valid ? real(1) : real(0);
-                const real rn = pend ? fma_(alpha, sv[s], rv[s]) : rv[s];
+                real rn = pend ? fma_(alpha, sv[s], rv[s]) : rv[s];
+                if constexpr (Dyn::ID != 0) {
+                    if (t < T - 1) rn = rtrue[s];
+                }
                 const real ln = dual ? fma_(rho, rn, lv[s]) : lv[s];
                 if (valid && active) {
-                    if (pend) rp[C::oR + r] = rn;
+                    if (pend || Dyn::ID != 0) rp[C::oR + r] = rn;
                     if (dual) rp[C::oLE + r] = ln;
                     if (write_out) glam[t * NX + r] = ln;
                 }

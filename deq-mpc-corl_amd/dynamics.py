@@ -13,6 +13,7 @@ from .backend import default_backend
 
 class Pendulum1lDynamics:
     nx, nu = 2, 1
+    fused_id = 1   # model id of the nonlinear fused solve (alqp_solve_nonlin)
 
     def __init__(self, dt=0.05, backend=None):
         self.dt = float(dt)
@@ -56,6 +57,7 @@ class Cartpole1lDynamics:
     pole angle, their rates), pole angle 0 = upright; the action drives the cart only
     (my_envs/dynamics.py:54-56), so tau = (u, 0)."""
     nx, nu = 4, 1
+    fused_id = 2
 
     def __init__(self, dt=0.05, backend=None):
         self.dt = float(dt)

@@ -493,6 +493,17 @@ class MPC(Module):
             npa = [MAX_NEWTON] * self.al_iter
             rho_last = st.rho / RHO_SCALE
             F_last = F
+        elif (F is None and not stream and self.exit_mode == "fixed" and not need_grad
+              and getattr(st.dx, "fused_id", None) is not None and hasattr(be, "solve_nonlin")
+              and (getattr(st.dx, "nx", None), getattr(st.dx, "nu", None)) == (nx, nu)):
+            # ---- nonlinear dynamics whose model is compiled into the library (dynamics.py): the
+            # whole nonlinear solve in ONE launch, no PyTorch round trip between Newton steps
+            be.solve_nonlin(dims, st.dx.fused_id, st.dx.dt, Qd, q, st.x0, lo, hi, sb, stt, st.z, st.lam, st.rho,
+                            ws["phi"], rnorm2=ws["rn2"], info=ws["info"], status=ws["status"],
+                            al_iter=self.al_iter, max_newton=MAX_NEWTON,
+                            flags=_abi.ALQP_INIT_MERIT | _abi.ALQP_DUAL_UPDATE, rho_scale=RHO_SCALE)
+            npa = [MAX_NEWTON] * self.al_iter
+            rho_last = st.rho / RHO_SCALE
         else:
             num_iters = 100 if linearize_once else self.al_iter
             prev_mean = None

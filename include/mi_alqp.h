@@ -229,6 +229,26 @@ int alqp_dyn_pendulum1l_f64(long K, const void *x, const void *u, double h, cons
 int alqp_dyn_cartpole1l_f32(long K, const void *x, const void *tau, double h, const void *h_pt, void *xnext, void *J, void *stream);
 int alqp_dyn_cartpole1l_f64(long K, const void *x, const void *tau, double h, const void *h_pt, void *xnext, void *J, void *stream);
 
+/*
+ * Nonlinear fused solve: the whole AL solve of MPC.al_solve (AL_mpc.py:260-339) with NONLINEAR
+ * dynamics in ONE launch, for the robots whose dynamics model is compiled into the library
+ * (dyn_id 1 = pendulum1l (nx=2, nu=1), 2 = cartpole1l (nx=4, nu=1, tau = (u, 0)); dyn_h = step length).
+ * Replaces the PyTorch round trips of NewtonAL.forward (al_utils.py:451-576): every Newton step
+ * re-linearises on the device (dx_jac, :503), the 20 line-search candidates and the dual update
+ * are evaluated with the true dynamics (:623-633, AL_mpc.py:315). Arguments as alqp_solve_lin
+ * without F, c; n_ls must be 20; workspace of alqp_workspace_bytes_nonlin() bytes; no
+ * ALQP_SAVE_FACTOR / ALQP_WS_PRIMED. Exit mode "fixed" (max_newton steps per AL iteration).
+ */
+size_t alqp_workspace_bytes_nonlin(const AlqpDims *dims, int is_f64);
+int alqp_solve_nonlin_f32(const AlqpDims *dims, const AlqpParams *prm, int dyn_id, double dyn_h, const void *Qd,
+                          const void *q, const void *x0, const void *u_lo, const void *u_hi, long sb_u, long st_u,
+                          void *z, void *lam, void *rho, void *phi, void *rnorm2, int *info, unsigned char *status,
+                          void *workspace, size_t ws_bytes, void *stream);
+int alqp_solve_nonlin_f64(const AlqpDims *dims, const AlqpParams *prm, int dyn_id, double dyn_h, const void *Qd,
+                          const void *q, const void *x0, const void *u_lo, const void *u_hi, long sb_u, long st_u,
+                          void *z, void *lam, void *rho, void *phi, void *rnorm2, int *info, unsigned char *status,
+                          void *workspace, size_t ws_bytes, void *stream);
+
 int alqp_abi_version(void);
 
 #ifdef __cplusplus

@@ -202,3 +202,53 @@ def test_hip_cartpole_class_and_package_twin():
     blocks = cartpole1l.derivatives(xa[:, :2].contiguous(), xa[:, 2:].contiguous(), ta, h)
     assert len(blocks) == 6 and all(b.shape == (xa.shape[0], 2, 2) for b in blocks)
     assert np.abs(blocks[4].cpu().numpy() - GOLDC["h05_J"][:, 2:, 2:4]).max() < 5e-13   # dqdot'/dqdot
+
+
+# ---- nonlinear fused solve (alqp_solve_nonlin) ----------------------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("env", ["pendulum1l", "cartpole1l"])
+@pytest.mark.parametrize("dtype,tol", [(torch.float64, 5e-7), (torch.float32, 2e-3)])
+def test_fused_nonlinear_solve_equals_the_launch_per_step_path(env, dtype, tol):
+    """One launch with the model inlined against the host-driven nonlinear-caller mode (kernel per
+    Newton-step phase, provider kernels for dx / dx_jac - the path that is validated against the
+    reference's nonlinear goldens), both with exit_mode='fixed'. Active bounds included."""
+    from deq_mpc_corl_amd import MPC, QuadCost, Pendulum1lDynamics, Cartpole1lDynamics
+    dev = "cuda:0"
+    prov = Pendulum1lDynamics(0.05) if env == "pendulum1l" else Cartpole1lDynamics(0.05)
+    nx, T, B = prov.nx, (6 if env == "pendulum1l" else 9), 70
+    n = nx + 1
+    g = torch.Generator().manual_seed(11)
+    x0 = (0.6 * torch.randn(B, nx, generator=g)).to(dtype).to(dev)
+    Qd = (0.5 + torch.rand(B, T, n, generator=g)).to(dtype).to(dev)
+    Qd[..., -1] = 0.05
+    q = (0.3 * torch.randn(B, T, n, generator=g)).to(dtype).to(dev)
+    ub = 0.4 if env == "pendulum1l" else 3.0          # tight: the bound rows become active
+
+    class Plain:                                        # same kernels, but no fused_id: launch-per-step path
+        def __call__(self, x, u):
+            return prov(x, u)
+
+        def jac(self, x, u):
+            return prov.jac(x, u)
+
+    res = {}
+    for name, dyn in (("fused", prov), ("stepwise", Plain())):
+        mpc = MPC(nx, 1, T, u_lower=-ub, u_upper=ub, n_batch=B, dtype=dtype, exit_mode="fixed")
+        mpc.reinitialize(x0, None)
+        mpc.al_iter = 3
+        cost = QuadCost(torch.diag_embed(Qd), q, torch.zeros(B, T, dtype=dtype, device=dev))
+        x, u, _ = mpc(x0, cost, dyn, dyn.jac)
+        res[name] = (x.double().cpu(), u.double().cpu(), mpc.lamda_prev.double().cpu(), mpc.rho_prev.double().cpu())
+    assert float(res["fused"][2][:, T * nx:].max()) > 0                      # bounds were active
+    if dtype == torch.float64:
+        # identical after one AL iteration (1e-16); afterwards the two factorisations (root-free LDL'
+        # here, Cholesky in the step kernel) differ by rounding, which rho = 10, 100 amplifies in lam,
+        # and x, u are returned in fp32 (AL_mpc.py:337-338): one fp32 ulp
+        assert torch.allclose(res["fused"][0], res["stepwise"][0], atol=5e-7)
+        assert torch.allclose(res["fused"][1], res["stepwise"][1], atol=5e-7)
+        assert torch.allclose(res["fused"][2], res["stepwise"][2], atol=2e-5, rtol=1e-6)
+    else:
+        # fp32: a near-tie in a 20-point line search may pick another candidate for single instances
+        err = (res["fused"][0] - res["stepwise"][0]).abs().reshape(B, -1).max(1).values
+        assert float(err.median()) < 1e-4 and float((err < tol).float().mean()) >= 0.9
+    assert torch.equal(res["fused"][3], res["stepwise"][3])

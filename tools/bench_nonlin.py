@@ -54,10 +54,21 @@ for name, nx, T, B, prov, ft in (("pendulum1l", 2, 5, 4096, Pendulum1lDynamics(h
     Qd[..., -1] = 0.1
     q = torch.zeros(B, T, n, dtype=dt, device=dev)
     cost = QuadCost(torch.diag_embed(Qd), q, torch.zeros(B, T, dtype=dt, device=dev))
-    for label, dx, dxj in (("hip provider", prov, prov.jac), ("pytorch + autograd", ft, autograd_jac(ft, nx))):
+    class Plain:   # the provider kernels without the model id: launch-per-phase path
+        def __call__(self, x, u):
+            return prov(x, u)
+
+        def jac(self, x, u):
+            return prov.jac(x, u)
+
+    plain = Plain()
+    for label, dx, dxj, mode in (("hip provider, reference exit", prov, prov.jac, "reference"),
+                                 ("pytorch + autograd, reference exit", ft, autograd_jac(ft, nx), "reference"),
+                                 ("hip provider, launch per phase, fixed 4 steps", plain, plain.jac, "fixed"),
+                                 ("model inlined: ONE launch (alqp_solve_nonlin), fixed 4 steps", prov, prov.jac, "fixed")):
         ts = []
         for rep in range(4):
-            mpc = MPC(nx, 1, T, u_lower=-5.0, u_upper=5.0, n_batch=B, dtype=dt)
+            mpc = MPC(nx, 1, T, u_lower=-5.0, u_upper=5.0, n_batch=B, dtype=dt, exit_mode=mode)
             mpc.reinitialize(x0, None)
             mpc.al_iter = 2
             torch.cuda.synchronize(); t0 = time.perf_counter()
