@@ -316,6 +316,18 @@ struct Quad {
                     }
                 }
             }
+            if (t == 0) {
+                // initial-state rows x_0 - x_init live in row block T-1 (al_utils.py:274); a merit
+                // evaluation may come before the first forward sweep rewrites them
+#pragma unroll
+                for (int s = 0; s < SW; ++s) {
+                    const int r = 4 * s + q;
+                    const real z0r = sel4(zt[4 * s], (4 * s + 1 < NX) ? zt[(4 * s + 1 < NX) ? 4 * s + 1 : 0] : real(0),
+                                          (4 * s + 2 < NX) ? zt[(4 * s + 2 < NX) ? 4 * s + 2 : 0] : real(0),
+                                          (4 * s + 3 < NX) ? zt[(4 * s + 3 < NX) ? 4 * s + 3 : 0] : real(0), q);
+                    if ((4 * s + 3 < NX || r < NX) && active) recp(T - 1)[C::oR + r] = z0r - gx0[(r < NX) ? r : NX - 1];
+                }
+            }
             if (dyn) {
                 real xn[NX], J[NX][N];
                 dyn_value_jac<Dyn, real>(zt, dyn_h, xn, J);

@@ -19,9 +19,9 @@ def load(name):
 
 
 def names(pattern="*"):
-    # dyn_*.npz belong to the dynamics-provider tests (tests/test_dynamics_provider.py)
+    # dyn_*.npz and *casadi* belong to the dynamics-provider tests (tests/test_dynamics_provider.py)
     return sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, pattern + ".npz"))
-                  if not os.path.basename(p).startswith("dyn_"))
+                  if not os.path.basename(p).startswith("dyn_") and "casadi" not in os.path.basename(p))
 
 
 def step_context(g):

@@ -128,11 +128,39 @@ def np_(t):
     return t.detach().cpu().numpy()
 
 
+class CasadiPendulum1l:
+    """dx / dx_jac callables over the REFERENCE's CasADi-generated pendulum1l code, compiled from its
+    own sources into oracle/_ref (make -C oracle ref) - i.e. what my_envs.dynamics.Dynamics does
+    with its `package` (my_envs/dynamics.py:60-75), on CPU tensors."""
+
+    def __init__(self, dt):
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        from oracle import dyn_py
+        dyn_py.build()
+        assert dyn_py.have_ref()
+        self.dt, self.dyn_py = dt, dyn_py
+
+    def __call__(self, x, u):
+        xn, _, _ = self.dyn_py.pendulum1l_ref(x.detach().double().numpy(), u.detach().double().numpy(), self.dt)
+        return torch.from_numpy(xn).to(x.dtype)
+
+    def jac(self, x, u):
+        xn, A, Bm = self.dyn_py.pendulum1l_ref(x.detach().double().numpy(), u.detach().double().numpy(), self.dt)
+        return torch.from_numpy(xn).to(x.dtype), (torch.from_numpy(A).to(x.dtype), torch.from_numpy(Bm).to(x.dtype))
+
+
+ONLY = os.environ.get("GOLDEN_ONLY", "")   # regenerate only the fixtures whose name contains this
+
+
 def run_case(name, B, T, nx, nu, dtype, al_iter, active=False, seed=0,
              backward=False, nonlinear=False, n_record_steps=None):
+    if ONLY and ONLY not in name:
+        return None
     n = nx + nu
     p = problems.synthetic_problem(B, T, nx, nu, seed=seed, dtype=dtype, active=active)
-    if nonlinear:
+    if nonlinear == "casadi_pendulum1l":
+        dyn = CasadiPendulum1l(0.05)
+    elif nonlinear:
         dyn = problems.PendulumDynamics()
     else:
         dyn = problems.AffineDynamics(p.F, p.c)
@@ -153,7 +181,7 @@ def run_case(name, B, T, nx, nu, dtype, al_iter, active=False, seed=0,
     out = {
         "B": B, "T": T, "nx": nx, "nu": nu, "al_iter": al_iter,
         "dtype": "f64" if dtype == torch.float64 else "f32",
-        "nonlinear": int(nonlinear), "active": int(active), "seed": seed,
+        "nonlinear": int(bool(nonlinear)), "active": int(active), "seed": seed,
         "Qd": np_(p.Qd), "q": np_(p.q), "F": np_(p.F), "c": np_(p.c), "x0": np_(p.x0),
         "u_lo": np_(p.u_lo), "u_hi": np_(p.u_hi), "z0": np_(p.z0),
         "x": np_(x), "u": np_(u), "status": int(bool(status)),
@@ -192,6 +220,8 @@ def run_case(name, B, T, nx, nu, dtype, al_iter, active=False, seed=0,
 
 
 def run_state_carry(name, B, T, nx, nu, dtype, calls=3):
+    if ONLY and ONLY not in name:
+        return None
     """reinitialize + successive __call__s: pins lamda/rho carry and rho growth
     (AL_mpc.py:256-257, 333-335) the way policies.Tracking_MPC drives the solver
     (policies.py:1242-1244, 1262, 1274)."""
@@ -230,6 +260,8 @@ def run_state_carry(name, B, T, nx, nu, dtype, calls=3):
 
 
 def run_tracking_mpc(name, B, T, nx, nu):
+    if ONLY and ONLY not in name:
+        return None
     """policies.Tracking_MPC end to end with a fake env/args (the adapter row of
     SURVEY.md §8b); falls back silently if policies.py cannot be imported."""
     try:
@@ -284,6 +316,9 @@ def main():
     # nonlinear-caller mode
     run_case("pend_nonlin_f64_al4", 8, 5, 2, 1, f64, 4, nonlinear=True, backward=True)
     run_case("pend_nonlin_f32_al2", 8, 5, 2, 1, f32, 2, nonlinear=True)
+    # the reference's own pendulum1l dynamics package (CasADi code compiled into oracle/_ref)
+    run_case("pend1l_casadi_f64_al2", 8, 6, 2, 1, f64, 2, nonlinear="casadi_pendulum1l", seed=int(os.environ.get("CASADI_SEED", "0")))
+    run_case("pend1l_casadi_active_f64_al3", 8, 6, 2, 1, f64, 3, nonlinear="casadi_pendulum1l", active=True, seed=2)
     run_state_carry("cart_carry_f64", 8, 10, 8, 2, f64)
     run_tracking_mpc("cart_tracking_f64", 8, 10, 8, 2)
 
