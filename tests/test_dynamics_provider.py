@@ -257,7 +257,8 @@ def test_fused_nonlinear_solve_equals_the_launch_per_step_path(env, dtype, tol):
 # ---- against the REFERENCE MPC driving its own compiled pendulum1l package ------------------
 import tests.golden_util as gu  # noqa: E402
 
-CASADI_GOLDENS = ["pend1l_casadi_f64_al2", "pend1l_casadi_active_f64_al3"]
+CASADI_GOLDENS = ["pend1l_casadi_f64_al2", "pend1l_casadi_active_f64_al3",
+                  "cart1l_casadi_f64_al2", "cart1l_casadi_active_f64_al3"]
 
 
 @pytest.mark.parametrize("name", CASADI_GOLDENS)
@@ -273,10 +274,14 @@ def test_host_logic_with_restated_dynamics_vs_reference_mpc(name):
 
     class Dyn:
         def __call__(self, x, u):
-            return torch.from_numpy(dyn_py.pendulum1l(x.numpy(), u.numpy(), 0.05)[0])
+            return self.jac(x, u)[0]
 
         def jac(self, x, u):
-            xn, A, Bm = dyn_py.pendulum1l(x.numpy(), u.numpy(), 0.05)
+            if name.startswith("pend"):
+                xn, A, Bm = dyn_py.pendulum1l(x.numpy(), u.numpy(), 0.05)
+            else:
+                xn, J = dyn_py.cartpole1l(x.numpy(), np.concatenate([u.numpy(), np.zeros((u.shape[0], 1))], 1), 0.05)
+                A, Bm = J[:, :, :4].copy(), J[:, :, 4:5].copy()
             return torch.from_numpy(xn), (torch.from_numpy(A), torch.from_numpy(Bm))
 
     tt = lambda a: torch.tensor(a, dtype=dt)
@@ -298,16 +303,19 @@ def test_host_logic_with_restated_dynamics_vs_reference_mpc(name):
 @pytest.mark.parametrize("name", CASADI_GOLDENS)
 @pytest.mark.parametrize("path", ["one launch (alqp_solve_nonlin)", "launch per phase, reference exit"])
 def test_gpu_nonlinear_paths_vs_reference_mpc(name, path):
-    """Both GPU routes of the nonlinear pendulum MPC against the reference MPC run on its own
-    compiled package (the reference executed all 4 Newton steps in every AL iteration of these
-    fixtures, so the fixed-4-step fused launch is comparable as well)."""
-    from deq_mpc_corl_amd import MPC, QuadCost, Pendulum1lDynamics
+    """Both GPU routes of the nonlinear MPC against the reference MPC run on its own compiled
+    pendulum1l / cartpole1l package. Where the reference executed all 4 Newton steps in every AL
+    iteration (the pendulum fixtures) the fixed-4-step fused launch is comparable as well; the
+    cartpole fixtures (early batch-global exits: [2,1] and [1,1,4] steps) pin the reference-exit
+    route and its step counts."""
+    from deq_mpc_corl_amd import MPC, QuadCost, Pendulum1lDynamics, Cartpole1lDynamics
     g = gu.load(name)
-    assert all(k == 4 for k in g["newton_per_al"])
+    if path.startswith("one launch") and not all(k == 4 for k in g["newton_per_al"]):
+        pytest.skip("the reference left its Newton loop early in this fixture: only the reference-exit route is comparable")
     dt, dev = torch.float64, "cuda:0"
     B, T, nx = g["B"], g["T"], g["nx"]
     tt = lambda a: torch.tensor(a, dtype=dt, device=dev)
-    prov = Pendulum1lDynamics(0.05)
+    prov = Pendulum1lDynamics(0.05) if name.startswith("pend") else Cartpole1lDynamics(0.05)
     mode = "fixed" if path.startswith("one launch") else "reference"
     mpc = MPC(nx, 1, T, u_lower=tt(g["u_lo"]), u_upper=tt(g["u_hi"]), n_batch=B, dtype=dt, exit_mode=mode)
     x0 = tt(g["x0"])

@@ -152,14 +152,46 @@ class CasadiPendulum1l:
 ONLY = os.environ.get("GOLDEN_ONLY", "")   # regenerate only the fixtures whose name contains this
 
 
+class CasadiCartpole1l:
+    """The same over the reference's compiled cartpole1l package; the action drives the cart only
+    (tau = (u, 0), my_envs/dynamics.py:54-56)."""
+
+    def __init__(self, dt):
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        from oracle import dyn_py
+        dyn_py.build()
+        assert dyn_py.have_ref_cartpole()
+        self.dt, self.dyn_py = dt, dyn_py
+
+    def _tau(self, u):
+        return np.concatenate([u.detach().double().numpy(), np.zeros((u.shape[0], 1))], 1)
+
+    def __call__(self, x, u):
+        xn, _ = self.dyn_py.cartpole1l_ref(x.detach().double().numpy(), self._tau(u), self.dt)
+        return torch.from_numpy(xn).to(x.dtype)
+
+    def jac(self, x, u):
+        xn, J = self.dyn_py.cartpole1l_ref(x.detach().double().numpy(), self._tau(u), self.dt)
+        return torch.from_numpy(xn).to(x.dtype), (torch.from_numpy(J[:, :, :4].copy()).to(x.dtype),
+                                                   torch.from_numpy(J[:, :, 4:5].copy()).to(x.dtype))
+
+
 def run_case(name, B, T, nx, nu, dtype, al_iter, active=False, seed=0,
              backward=False, nonlinear=False, n_record_steps=None):
     if ONLY and ONLY not in name:
         return None
     n = nx + nu
     p = problems.synthetic_problem(B, T, nx, nu, seed=seed, dtype=dtype, active=active)
+    if nonlinear == "casadi_cartpole1l":
+        # the synthetic N(0,1) reference trajectory is far from anything a cartpole can do (the
+        # reference's batch-global exit test then stops after one step): a milder instance of the
+        # same shape, so that all four Newton steps run and the fixed-step kernel is comparable
+        sc = 0.15
+        p = p._replace(x0=sc * p.x0, z0=sc * p.z0, xref=sc * p.xref, q=-(p.Qd * sc * p.xref))
     if nonlinear == "casadi_pendulum1l":
         dyn = CasadiPendulum1l(0.05)
+    elif nonlinear == "casadi_cartpole1l":
+        dyn = CasadiCartpole1l(0.05)
     elif nonlinear:
         dyn = problems.PendulumDynamics()
     else:
@@ -319,6 +351,8 @@ def main():
     # the reference's own pendulum1l dynamics package (CasADi code compiled into oracle/_ref)
     run_case("pend1l_casadi_f64_al2", 8, 6, 2, 1, f64, 2, nonlinear="casadi_pendulum1l", seed=int(os.environ.get("CASADI_SEED", "0")))
     run_case("pend1l_casadi_active_f64_al3", 8, 6, 2, 1, f64, 3, nonlinear="casadi_pendulum1l", active=True, seed=2)
+    run_case("cart1l_casadi_f64_al2", 6, 8, 4, 1, f64, 2, nonlinear="casadi_cartpole1l", seed=int(os.environ.get("CASADI_SEED", "1")))
+    run_case("cart1l_casadi_active_f64_al3", 6, 8, 4, 1, f64, 3, nonlinear="casadi_cartpole1l", active=True, seed=3)
     run_state_carry("cart_carry_f64", 8, 10, 8, 2, f64)
     run_tracking_mpc("cart_tracking_f64", 8, 10, 8, 2)
 
