@@ -129,7 +129,7 @@ class HipBackend:
 
     def solve_nonlin(self, dims, dyn_id, dyn_h, Qd, q, x0, ulo, uhi, sb_u, st_u, z, lam, rho, phi, rnorm2=None,
                      info=None, status=None, al_iter=2, max_newton=4,
-                     flags=_lib.ALQP_INIT_MERIT | _lib.ALQP_DUAL_UPDATE, rho_scale=10.0):
+                     flags=_lib.ALQP_INIT_MERIT | _lib.ALQP_DUAL_UPDATE, rho_scale=10.0, skip=None):
         """Nonlinear fused solve (alqp_solve_nonlin): the dynamics model `dyn_id` is inlined."""
         B, T, nx, nu = dims
         dt = z.dtype
@@ -143,7 +143,8 @@ class HipBackend:
         if ws is None or ws.numel() * ws.element_size() < need:
             ws = torch.empty(need // z.element_size() + 16, dtype=dt, device=z.device)
             self._ws[key] = ws
-        p = _lib.AlqpParams(al_iter, max_newton, 20, flags, rho_scale, 2, None)
+        skp = _ptr(skip, "skip", torch.float64, True)
+        p = _lib.AlqpParams(al_iter, max_newton, 20, flags, rho_scale, 2, skp.value if skp is not None else None)
         fn = getattr(self.lib, "alqp_solve_nonlin_" + sfx)
         rc = fn(C.byref(d), C.byref(p), int(dyn_id), float(dyn_h), _ptr(Qd, "Qd", dt), _ptr(q, "q", dt), _ptr(x0, "x0", dt),
                 _ptr(ulo, "u_lower", dt), _ptr(uhi, "u_upper", dt), sb_u, st_u, _ptr(z, "z", dt), _ptr(lam, "lam", dt),

@@ -385,6 +385,22 @@ class MPC(Module):
             be.exit_test(self._global_sumsq(ws["rn2"]), ctl, 1)
         return ctl
 
+    def _newton_al_fused_nl(self, st, Qd, q, bnd, ws):
+        """NewtonAL.forward for a dynamics model compiled into the library, reference exit rule:
+        alqp_solve_nonlin once per Newton step, alqp_exit_test in between (no host round trip)."""
+        be = self.backend
+        dims = (st.z.shape[0], self.T, self.n_state, self.n_ctrl)
+        lo, hi, sb, stt = bnd
+        common = dict(rnorm2=ws["rn2"], info=ws["info"], status=ws["status"], rho_scale=RHO_SCALE)
+        args = (dims, st.dx.fused_id, st.dx.dt, Qd, q, st.x0, lo, hi, sb, stt, st.z, st.lam, st.rho, ws["phi"])
+        be.solve_nonlin(*args, al_iter=1, max_newton=0, flags=_abi.ALQP_INIT_MERIT, **common)
+        ctl = torch.zeros(3, dtype=torch.float64, device=st.z.device)
+        be.exit_test(self._global_sumsq(ws["rn2"]), ctl, 0)
+        for _ in range(MAX_NEWTON):
+            be.solve_nonlin(*args, al_iter=1, max_newton=1, flags=0, skip=ctl, **common)
+            be.exit_test(self._global_sumsq(ws["rn2"]), ctl, 1)
+        return ctl
+
     def _newton_al_nonlin(self, st, Qd, q, bnd, ws, need_factor):
         """NewtonAL.forward (al_utils.py:451-576) with `dx`/`dx_jac` as PyTorch calls
         between kernel launches."""
@@ -512,8 +528,19 @@ class MPC(Module):
                 be.merit(dims, 1, st.z, xn, st.x0, st.lam, st.rho, Qd, q, lo, hi, sb, stt,
                          ws["phi"], ws["rn2"])
                 prev_mean = float(ws["rn2"].sqrt().mean().item())
+            fused_nl = (F is None and not stream and not need_grad and self.exit_mode == "reference"
+                        and getattr(st.dx, "fused_id", None) is not None and hasattr(be, "solve_nonlin")
+                        and (getattr(st.dx, "nx", None), getattr(st.dx, "nu", None)) == (nx, nu))
             for _ in range(num_iters):
                 rho_last = st.rho.clone()
+                if fused_nl:
+                    # compiled-in model, reference exit: one launch per Newton step (the model inlined),
+                    # the batch-global exit test on the device, then the dual update launch
+                    npa.append(self._newton_al_fused_nl(st, Qd, q, bnd, ws))
+                    be.solve_nonlin(dims, st.dx.fused_id, st.dx.dt, Qd, q, st.x0, lo, hi, sb, stt, st.z, st.lam,
+                                    st.rho, ws["phi"], rnorm2=ws["rn2"], info=None, status=ws["status"],
+                                    al_iter=1, max_newton=0, flags=_abi.ALQP_DUAL_UPDATE, rho_scale=RHO_SCALE)
+                    continue
                 if F is not None:
                     npa.append(self._newton_al_lin(st, Qd, q, F, c, bnd, ws, need_grad))
                     F_last = F

@@ -301,7 +301,8 @@ def test_host_logic_with_restated_dynamics_vs_reference_mpc(name):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("name", CASADI_GOLDENS)
-@pytest.mark.parametrize("path", ["one launch (alqp_solve_nonlin)", "launch per phase, reference exit"])
+@pytest.mark.parametrize("path", ["one launch (alqp_solve_nonlin)", "one launch per Newton step, reference exit",
+                                  "provider kernels, launch per phase, reference exit"])
 def test_gpu_nonlinear_paths_vs_reference_mpc(name, path):
     """Both GPU routes of the nonlinear MPC against the reference MPC run on its own compiled
     pendulum1l / cartpole1l package. Where the reference executed all 4 Newton steps in every AL
@@ -310,13 +311,23 @@ def test_gpu_nonlinear_paths_vs_reference_mpc(name, path):
     route and its step counts."""
     from deq_mpc_corl_amd import MPC, QuadCost, Pendulum1lDynamics, Cartpole1lDynamics
     g = gu.load(name)
-    if path.startswith("one launch") and not all(k == 4 for k in g["newton_per_al"]):
+    if path.startswith("one launch (") and not all(k == 4 for k in g["newton_per_al"]):
         pytest.skip("the reference left its Newton loop early in this fixture: only the reference-exit route is comparable")
     dt, dev = torch.float64, "cuda:0"
     B, T, nx = g["B"], g["T"], g["nx"]
     tt = lambda a: torch.tensor(a, dtype=dt, device=dev)
     prov = Pendulum1lDynamics(0.05) if name.startswith("pend") else Cartpole1lDynamics(0.05)
-    mode = "fixed" if path.startswith("one launch") else "reference"
+    mode = "fixed" if path.startswith("one launch (") else "reference"
+    if path.startswith("provider kernels"):
+        class Plain:            # no fused_id: dx / dx_jac as plain callables between kernel launches
+            def __call__(self, x, u):
+                return prov_k(x, u)
+
+            def jac(self, x, u):
+                return prov_k.jac(x, u)
+
+        prov_k, prov = prov, None
+        prov = Plain()
     mpc = MPC(nx, 1, T, u_lower=tt(g["u_lo"]), u_upper=tt(g["u_hi"]), n_batch=B, dtype=dt, exit_mode=mode)
     x0 = tt(g["x0"])
     mpc.reinitialize(x0, None)

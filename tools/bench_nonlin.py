@@ -62,9 +62,10 @@ for name, nx, T, B, prov, ft in (("pendulum1l", 2, 5, 4096, Pendulum1lDynamics(h
             return prov.jac(x, u)
 
     plain = Plain()
-    for label, dx, dxj, mode in (("hip provider, reference exit", prov, prov.jac, "reference"),
+    for label, dx, dxj, mode in (("model inlined: one launch per Newton step, exit test on the device (reference exit)", prov, prov.jac, "reference"),
                                  ("pytorch + autograd, reference exit", ft, autograd_jac(ft, nx), "reference"),
-                                 ("hip provider, launch per phase, fixed 4 steps", plain, plain.jac, "fixed"),
+                                 ("provider kernels for dx/dx_jac, launch per phase, reference exit", plain, plain.jac, "reference"),
+                                 ("provider kernels for dx/dx_jac, launch per phase, fixed 4 steps", plain, plain.jac, "fixed"),
                                  ("model inlined: ONE launch (alqp_solve_nonlin), fixed 4 steps", prov, prov.jac, "fixed")):
         ts = []
         for rep in range(4):
