@@ -129,8 +129,10 @@ class HipBackend:
 
     def solve_nonlin(self, dims, dyn_id, dyn_h, Qd, q, x0, ulo, uhi, sb_u, st_u, z, lam, rho, phi, rnorm2=None,
                      info=None, status=None, al_iter=2, max_newton=4,
-                     flags=_lib.ALQP_INIT_MERIT | _lib.ALQP_DUAL_UPDATE, rho_scale=10.0, skip=None):
-        """Nonlinear fused solve (alqp_solve_nonlin): the dynamics model `dyn_id` is inlined."""
+                     flags=_lib.ALQP_INIT_MERIT | _lib.ALQP_DUAL_UPDATE, rho_scale=10.0, skip=None, workspace=None):
+        """Nonlinear fused solve (alqp_solve_nonlin): the dynamics model `dyn_id` is inlined.
+        workspace: a private one (new_workspace_nonlin) when the factor and linearisation it holds
+        afterwards are needed by backward_ws; default: a cached one."""
         B, T, nx, nu = dims
         dt = z.dtype
         sfx = _dt(z)
@@ -138,11 +140,16 @@ class HipBackend:
         need = int(self.lib.alqp_workspace_bytes_nonlin(C.byref(d), int(dt == torch.float64)))
         if need == 0:
             raise RuntimeError("mi_alqp: nonlinear fused solve not available for these sizes")
-        key = ("nl", z.device, dt)
-        ws = self._ws.get(key)
-        if ws is None or ws.numel() * ws.element_size() < need:
-            ws = torch.empty(need // z.element_size() + 16, dtype=dt, device=z.device)
-            self._ws[key] = ws
+        if workspace is not None:
+            ws = workspace
+            if ws.numel() * ws.element_size() < need:
+                raise ValueError("mi_alqp: workspace too small")
+        else:
+            key = ("nl", z.device, dt)
+            ws = self._ws.get(key)
+            if ws is None or ws.numel() * ws.element_size() < need:
+                ws = torch.empty(need // z.element_size() + 16, dtype=dt, device=z.device)
+                self._ws[key] = ws
         skp = _ptr(skip, "skip", torch.float64, True)
         p = _lib.AlqpParams(al_iter, max_newton, 20, flags, rho_scale, 2, skp.value if skp is not None else None)
         fn = getattr(self.lib, "alqp_solve_nonlin_" + sfx)
@@ -252,6 +259,20 @@ class HipBackend:
                 _ptr(Qd_grad, "Qd_grad", dt), _stream())
         _lib.check(rc, "alqp_backward_" + sfx)
 
+
+    def new_workspace_nonlin(self, dims, like):
+        """A private workspace for nonlinear fused solves: [records | F linearisations]."""
+        B, T, nx, nu = dims
+        d = _lib.AlqpDims(B, T, nx, nu)
+        need = int(self.lib.alqp_workspace_bytes_nonlin(C.byref(d), int(like.dtype == torch.float64)))
+        return torch.empty(need // like.element_size() + 16, dtype=like.dtype, device=like.device)
+
+    def nonlin_F_view(self, ws, dims):
+        """The F region of a nonlinear workspace as a [B, T-1, nx, n] tensor (the linearisation of the
+        last executed Newton step, next to its factor in the records)."""
+        B, T, nx, nu = dims
+        off = self.workspace_bytes(B, T, nx, nu, ws.dtype) // ws.element_size()
+        return ws[off:off + B * (T - 1) * nx * (nx + nu)].view(B, T - 1, nx, nx + nu)
 
     def new_workspace(self, dims, like):
         """A private workspace for one quad solve whose factor will be used by backward_ws."""

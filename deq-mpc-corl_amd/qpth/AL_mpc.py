@@ -391,7 +391,8 @@ class MPC(Module):
         be = self.backend
         dims = (st.z.shape[0], self.T, self.n_state, self.n_ctrl)
         lo, hi, sb, stt = bnd
-        common = dict(rnorm2=ws["rn2"], info=ws["info"], status=ws["status"], rho_scale=RHO_SCALE)
+        common = dict(rnorm2=ws["rn2"], info=ws["info"], status=ws["status"], rho_scale=RHO_SCALE,
+                      workspace=ws.get("nlws"))
         args = (dims, st.dx.fused_id, st.dx.dt, Qd, q, st.x0, lo, hi, sb, stt, st.z, st.lam, st.rho, ws["phi"])
         be.solve_nonlin(*args, al_iter=1, max_newton=0, flags=_abi.ALQP_INIT_MERIT, **common)
         ctl = torch.zeros(3, dtype=torch.float64, device=st.z.device)
@@ -509,17 +510,22 @@ class MPC(Module):
             npa = [MAX_NEWTON] * self.al_iter
             rho_last = st.rho / RHO_SCALE
             F_last = F
-        elif (F is None and not stream and self.exit_mode == "fixed" and not need_grad
+        elif (F is None and not stream and self.exit_mode == "fixed"
               and getattr(st.dx, "fused_id", None) is not None and hasattr(be, "solve_nonlin")
               and (getattr(st.dx, "nx", None), getattr(st.dx, "nu", None)) == (nx, nu)):
             # ---- nonlinear dynamics whose model is compiled into the library (dynamics.py): the
             # whole nonlinear solve in ONE launch, no PyTorch round trip between Newton steps
+            if need_grad:   # private workspace: its records and F region are the saved factor
+                ws["nlws"] = be.new_workspace_nonlin(dims, st.z)
             be.solve_nonlin(dims, st.dx.fused_id, st.dx.dt, Qd, q, st.x0, lo, hi, sb, stt, st.z, st.lam, st.rho,
                             ws["phi"], rnorm2=ws["rn2"], info=ws["info"], status=ws["status"],
                             al_iter=self.al_iter, max_newton=MAX_NEWTON,
-                            flags=_abi.ALQP_INIT_MERIT | _abi.ALQP_DUAL_UPDATE, rho_scale=RHO_SCALE)
+                            flags=_abi.ALQP_INIT_MERIT | _abi.ALQP_DUAL_UPDATE, rho_scale=RHO_SCALE,
+                            workspace=ws.get("nlws"))
             npa = [MAX_NEWTON] * self.al_iter
             rho_last = st.rho / RHO_SCALE
+            if need_grad:
+                F_last = be.nonlin_F_view(ws["nlws"], dims)
         else:
             num_iters = 100 if linearize_once else self.al_iter
             prev_mean = None
@@ -528,7 +534,7 @@ class MPC(Module):
                 be.merit(dims, 1, st.z, xn, st.x0, st.lam, st.rho, Qd, q, lo, hi, sb, stt,
                          ws["phi"], ws["rn2"])
                 prev_mean = float(ws["rn2"].sqrt().mean().item())
-            fused_nl = (F is None and not stream and not need_grad and self.exit_mode == "reference"
+            fused_nl = (F is None and not stream and self.exit_mode == "reference"
                         and getattr(st.dx, "fused_id", None) is not None and hasattr(be, "solve_nonlin")
                         and (getattr(st.dx, "nx", None), getattr(st.dx, "nu", None)) == (nx, nu))
             for _ in range(num_iters):
@@ -536,10 +542,15 @@ class MPC(Module):
                 if fused_nl:
                     # compiled-in model, reference exit: one launch per Newton step (the model inlined),
                     # the batch-global exit test on the device, then the dual update launch
+                    if need_grad and "nlws" not in ws:
+                        ws["nlws"] = be.new_workspace_nonlin(dims, st.z)
                     npa.append(self._newton_al_fused_nl(st, Qd, q, bnd, ws))
                     be.solve_nonlin(dims, st.dx.fused_id, st.dx.dt, Qd, q, st.x0, lo, hi, sb, stt, st.z, st.lam,
                                     st.rho, ws["phi"], rnorm2=ws["rn2"], info=None, status=ws["status"],
-                                    al_iter=1, max_newton=0, flags=_abi.ALQP_DUAL_UPDATE, rho_scale=RHO_SCALE)
+                                    al_iter=1, max_newton=0, flags=_abi.ALQP_DUAL_UPDATE, rho_scale=RHO_SCALE,
+                                    workspace=ws.get("nlws"))
+                    if need_grad:   # L and F of the last executed Newton step are still in the workspace
+                        F_last = be.nonlin_F_view(ws["nlws"], dims)
                     continue
                 if F is not None:
                     npa.append(self._newton_al_lin(st, Qd, q, F, c, bnd, ws, need_grad))
@@ -584,6 +595,8 @@ class MPC(Module):
         self.last_info = ws["info"]
         self.dyn_res_prev = ws["rn2"].sqrt()
         if need_grad and F_last is not None:
+            if "nlws" in ws:
+                return "workspace", ws["nlws"], F_last, rho_last
             if use_qws:
                 return "workspace", ws["qws"], F_last, rho_last
             return "packed", ws["factor"], F_last, rho_last

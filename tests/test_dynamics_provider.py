@@ -290,10 +290,16 @@ def test_host_logic_with_restated_dynamics_vs_reference_mpc(name):
     mpc.reinitialize(x0, None)
     mpc.al_iter = g["al_iter"]
     z0 = tt(g["z0"])
-    cost = QuadCost(torch.diag_embed(tt(g["Qd"])), tt(g["q"]), torch.zeros(B, T, dtype=dt))
+    Qd = tt(g["Qd"]).requires_grad_(True)
+    q = tt(g["q"]).requires_grad_(True)
+    cost = QuadCost(torch.diag_embed(Qd), q, torch.zeros(B, T, dtype=dt))
     dyn = Dyn()
     x, u, _ = mpc(x0, cost, dyn, dyn.jac, x_init=z0[..., :nx].clone(), u_init=z0[..., nx:].clone())
     assert list(mpc.last_newton_per_al) == list(g["newton_per_al"])
+    ((x * torch.tensor(g["bwd_wx"])).sum() + (u * torch.tensor(g["bwd_wu"])).sum()).backward()
+    assert np.abs(q.grad.numpy() - g["bwd_q_grad"]).max() < 1e-5 * np.abs(g["bwd_q_grad"]).max()
+    assert np.abs(Qd.grad.numpy() - g["bwd_Qd_grad"]).max() < 1e-5 * np.abs(g["bwd_Qd_grad"]).max()
+    x, u = x.detach(), u.detach()
     assert np.abs(x.numpy() - g["x"]).max() < 2e-5 and np.abs(u.numpy() - g["u"]).max() < 2e-5
     assert np.abs(mpc.lamda_prev.numpy() - g["lam_final"]).max() < 1e-6 * max(1.0, np.abs(g["lam_final"]).max())
     assert np.array_equal(mpc.rho_prev.numpy().reshape(-1), g["rho_final"].reshape(-1))
@@ -303,7 +309,8 @@ def test_host_logic_with_restated_dynamics_vs_reference_mpc(name):
 @pytest.mark.parametrize("name", CASADI_GOLDENS)
 @pytest.mark.parametrize("path", ["one launch (alqp_solve_nonlin)", "one launch per Newton step, reference exit",
                                   "provider kernels, launch per phase, reference exit"])
-def test_gpu_nonlinear_paths_vs_reference_mpc(name, path):
+@pytest.mark.parametrize("with_grad", [False, True])
+def test_gpu_nonlinear_paths_vs_reference_mpc(name, path, with_grad):
     """Both GPU routes of the nonlinear MPC against the reference MPC run on its own compiled
     pendulum1l / cartpole1l package. Where the reference executed all 4 Newton steps in every AL
     iteration (the pendulum fixtures) the fixed-4-step fused launch is comparable as well; the
@@ -333,9 +340,18 @@ def test_gpu_nonlinear_paths_vs_reference_mpc(name, path):
     mpc.reinitialize(x0, None)
     mpc.al_iter = g["al_iter"]
     z0 = tt(g["z0"])
-    cost = QuadCost(torch.diag_embed(tt(g["Qd"])), tt(g["q"]), torch.zeros(B, T, dtype=dt, device=dev))
+    Qd, q = tt(g["Qd"]), tt(g["q"])
+    if with_grad:   # NewtonAL.backward (al_utils.py:578-615): gradients w.r.t. q and diag Q from the saved factor
+        Qd.requires_grad_(True)
+        q.requires_grad_(True)
+    cost = QuadCost(torch.diag_embed(Qd), q, torch.zeros(B, T, dtype=dt, device=dev))
     x, u, _ = mpc(x0, cost, prov, prov.jac, x_init=z0[..., :nx].clone(), u_init=z0[..., nx:].clone())
     assert list(mpc.last_newton_per_al) == list(g["newton_per_al"])
+    if with_grad:
+        ((x * torch.tensor(g["bwd_wx"], device=dev)).sum() + (u * torch.tensor(g["bwd_wu"], device=dev)).sum()).backward()
+        assert np.abs(q.grad.cpu().numpy() - g["bwd_q_grad"]).max() < 1e-5 * np.abs(g["bwd_q_grad"]).max()
+        assert np.abs(Qd.grad.cpu().numpy() - g["bwd_Qd_grad"]).max() < 1e-5 * np.abs(g["bwd_Qd_grad"]).max()
+        x, u = x.detach(), u.detach()
     assert np.abs(x.cpu().numpy() - g["x"]).max() < 2e-5 and np.abs(u.cpu().numpy() - g["u"]).max() < 2e-5
     assert np.abs(mpc.lamda_prev.cpu().numpy() - g["lam_final"]).max() < 1e-6 * max(1.0, np.abs(g["lam_final"]).max())
     assert np.array_equal(mpc.rho_prev.cpu().numpy().reshape(-1), g["rho_final"].reshape(-1))

@@ -349,10 +349,10 @@ def main():
     run_case("pend_nonlin_f64_al4", 8, 5, 2, 1, f64, 4, nonlinear=True, backward=True)
     run_case("pend_nonlin_f32_al2", 8, 5, 2, 1, f32, 2, nonlinear=True)
     # the reference's own pendulum1l dynamics package (CasADi code compiled into oracle/_ref)
-    run_case("pend1l_casadi_f64_al2", 8, 6, 2, 1, f64, 2, nonlinear="casadi_pendulum1l", seed=int(os.environ.get("CASADI_SEED", "0")))
-    run_case("pend1l_casadi_active_f64_al3", 8, 6, 2, 1, f64, 3, nonlinear="casadi_pendulum1l", active=True, seed=2)
-    run_case("cart1l_casadi_f64_al2", 6, 8, 4, 1, f64, 2, nonlinear="casadi_cartpole1l", seed=int(os.environ.get("CASADI_SEED", "1")))
-    run_case("cart1l_casadi_active_f64_al3", 6, 8, 4, 1, f64, 3, nonlinear="casadi_cartpole1l", active=True, seed=3)
+    run_case("pend1l_casadi_f64_al2", 8, 6, 2, 1, f64, 2, nonlinear="casadi_pendulum1l", seed=int(os.environ.get("CASADI_SEED", "0")), backward=True)
+    run_case("pend1l_casadi_active_f64_al3", 8, 6, 2, 1, f64, 3, nonlinear="casadi_pendulum1l", active=True, seed=2, backward=True)
+    run_case("cart1l_casadi_f64_al2", 6, 8, 4, 1, f64, 2, nonlinear="casadi_cartpole1l", seed=int(os.environ.get("CASADI_SEED", "1")), backward=True)
+    run_case("cart1l_casadi_active_f64_al3", 6, 8, 4, 1, f64, 3, nonlinear="casadi_cartpole1l", active=True, seed=3, backward=True)
     run_state_carry("cart_carry_f64", 8, 10, 8, 2, f64)
     run_tracking_mpc("cart_tracking_f64", 8, 10, 8, 2)
 
