@@ -47,6 +47,7 @@ _SIGS = {
                                     C.c_long, C.c_long, _P, _P, _P, _P, _P, _P, _P, _P, C.c_size_t, _P]),
     "alqp_dyn_pendulum1l": (C.c_int, [C.c_long, _P, _P, C.c_double, _P, _P, _P, _P]),
     "alqp_dyn_cartpole1l": (C.c_int, [C.c_long, _P, _P, C.c_double, _P, _P, _P, _P]),
+    "alqp_dyn_cartpole2l": (C.c_int, [C.c_long, _P, _P, C.c_double, _P, _P, _P, _P]),
     "alqp_solve_lin": (C.c_int, [C.POINTER(AlqpDims), C.POINTER(AlqpParams), _P, _P, _P, _P, _P, _P, _P,
                                  C.c_long, C.c_long, _P, _P, _P, _P, _P, _P, _P, _P,
                                  C.POINTER(AlqpTrace), _P, C.c_size_t, _P]),

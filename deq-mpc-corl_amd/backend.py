@@ -193,6 +193,21 @@ class HipBackend:
         _lib.check(rc, "alqp_dyn_cartpole1l")
         return xn, J
 
+    def dyn_cartpole2l(self, x, tau, h, want_jac=True):
+        """cartpole2l provider (alqp_dyn_cartpole2l): x [K,6], tau [K,3] -> xnext [K,6], J [K,6,9] or None."""
+        K = x.shape[0]
+        dt = x.dtype
+        xn = torch.empty(K, 6, dtype=dt, device=x.device)
+        J = torch.empty(K, 6, 9, dtype=dt, device=x.device) if want_jac else None
+        hpt = h.to(dt).reshape(-1).contiguous() if torch.is_tensor(h) else None
+        if hpt is not None and hpt.numel() != K:
+            raise ValueError("mi_alqp: h must be a number or one value per point")
+        fn = getattr(self.lib, "alqp_dyn_cartpole2l_" + _dt(x))
+        rc = fn(K, _ptr(x, "x", dt), _ptr(tau, "tau", dt), 0.0 if hpt is not None else float(h), _ptr(hpt, "h", dt, True),
+                _ptr(xn, "xnext", dt), _ptr(J, "J", dt, True), _stream())
+        _lib.check(rc, "alqp_dyn_cartpole2l")
+        return xn, J
+
     def exit_test(self, sumsq, ctl, mode, tol=1e-3):
         """Device-side batch-global exit test (alqp_exit_test): sumsq 0-d/1-elem float64 tensor,
         ctl float64[3] = {done, steps, old_norm}; nothing is synchronised."""

@@ -118,6 +118,101 @@ struct DynCartpole1l {
     }
 };
 
+// ---- cartpole2l: q = (cart x, th1, th2 relative to link 1), x = (q, q'), u = force on the cart -----
+//      M(q) q'' = tau - h(q, q') + G(q)   (model: oracle/dyn_oracle.c)
+template <typename real>
+struct DynCartpole2l {
+    static constexpr int NX = 6, NU = 1, ID = 3;
+    template <int NT>
+    __device__ __forceinline__ static Dual<real, NT> neg(Dual<real, NT> a) {
+        return daxpy(dconst<real, NT>(0), real(-1), a);
+    }
+    template <int NT>
+    __device__ __forceinline__ static Dual<real, NT> lin2(real a, Dual<real, NT> x, real b, Dual<real, NT> y) {  // a x + b y
+        return daxpy(daxpy(dconst<real, NT>(0), a, x), b, y);
+    }
+    template <int NT>
+    __device__ __forceinline__ static void acc(const Dual<real, NT> (&q)[3], const Dual<real, NT> (&w)[3],
+                                               const Dual<real, NT> (&tau)[3], Dual<real, NT> (&a)[3]) {
+        using D = Dual<real, NT>;
+        D s1, c1, s2, c2, s12, c12;
+        dsincos(q[1], s1, c1);
+        dsincos(q[2], s2, c2);
+        dsincos(daxpy(q[1], real(1), q[2]), s12, c12);
+        const D m11 = dconst<real, NT>(real(12)), m12 = neg(lin2(real(2), c1, real(1), c12)), m13 = neg(c12);
+        const D m22 = daxpy(dconst<real, NT>(real(5)), real(2), c2), m23 = daxpy(dconst<real, NT>(real(2)), real(1), c2);
+        const D m33 = dconst<real, NT>(real(2));
+        const D w12 = daxpy(w[1], real(1), w[2]);
+        const D r0 = daxpy(tau[0], real(-1), lin2(real(2), dmul(s1, dmul(w[1], w[1])), real(1), dmul(s12, dmul(w12, w12))));
+        const D r1 = daxpy(daxpy(tau[1], real(1), dmul(s2, dmul(w[2], daxpy(w[2], real(2), w[1])))), real(9.81),
+                           lin2(real(2), s1, real(1), s12));
+        const D r2 = daxpy(daxpy(tau[2], real(-1), dmul(s2, dmul(w[1], w[1]))), real(9.81), s12);
+        // symmetric 3x3 solve by cofactors
+        const D A00 = daxpy(dmul(m22, m33), real(-1), dmul(m23, m23));
+        const D A01 = daxpy(dmul(m13, m23), real(-1), dmul(m12, m33));
+        const D A02 = daxpy(dmul(m12, m23), real(-1), dmul(m13, m22));
+        const D A11 = daxpy(dmul(m11, m33), real(-1), dmul(m13, m13));
+        const D A12 = daxpy(dmul(m12, m13), real(-1), dmul(m11, m23));
+        const D A22 = daxpy(dmul(m11, m22), real(-1), dmul(m12, m12));
+        const D det = daxpy(daxpy(dmul(m11, A00), real(1), dmul(m12, A01)), real(1), dmul(m13, A02));
+        D idet;
+        idet.v = real(1) / det.v;
+#pragma unroll
+        for (int i = 0; i < NT; ++i) idet.d[i] = -det.d[i] * idet.v * idet.v;
+        a[0] = dmul(idet, daxpy(daxpy(dmul(A00, r0), real(1), dmul(A01, r1)), real(1), dmul(A02, r2)));
+        a[1] = dmul(idet, daxpy(daxpy(dmul(A01, r0), real(1), dmul(A11, r1)), real(1), dmul(A12, r2)));
+        a[2] = dmul(idet, daxpy(daxpy(dmul(A02, r0), real(1), dmul(A12, r1)), real(1), dmul(A22, r2)));
+    }
+    // full interface of the generated package: x[6], tau[3]
+    template <int NT>
+    __device__ __forceinline__ static void step_full(const Dual<real, NT> (&x)[6], const Dual<real, NT> (&tau)[3], real h,
+                                                     Dual<real, NT> (&xn)[6]) {
+        using D = Dual<real, NT>;
+        const real hh = real(0.5) * h, two = real(2), h6 = h / real(6);
+        D q[3], w[3], k1w[3], k2q[3], k2w[3], k3q[3], k3w[3], k4q[3], k4w[3], tq[3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            q[i] = x[i];
+            w[i] = x[3 + i];
+        }
+        acc(q, w, tau, k1w);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            tq[i] = daxpy(q[i], hh, w[i]);
+            k2q[i] = daxpy(w[i], hh, k1w[i]);
+        }
+        acc(tq, k2q, tau, k2w);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            tq[i] = daxpy(q[i], hh, k2q[i]);
+            k3q[i] = daxpy(w[i], hh, k2w[i]);
+        }
+        acc(tq, k3q, tau, k3w);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            tq[i] = daxpy(q[i], h, k3q[i]);
+            k4q[i] = daxpy(w[i], h, k3w[i]);
+        }
+        acc(tq, k4q, tau, k4w);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            xn[i] = daxpy(q[i], h6, daxpy(daxpy(w[i], two, k2q[i]), real(1), daxpy(k4q[i], two, k3q[i])));
+            xn[3 + i] = daxpy(w[i], h6, daxpy(daxpy(k1w[i], two, k2w[i]), real(1), daxpy(k4w[i], two, k3w[i])));
+        }
+    }
+    // MPC interface: z = (x[6], u), tau = (u, 0, 0)
+    template <int NT>
+    __device__ __forceinline__ static void step(const Dual<real, NT> (&z)[7], real h, Dual<real, NT> (&xn)[6]) {
+        Dual<real, NT> x[6], tau[3];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) x[i] = z[i];
+        tau[0] = z[6];
+        tau[1] = dconst<real, NT>(0);
+        tau[2] = dconst<real, NT>(0);
+        step_full<NT>(x, tau, h, xn);
+    }
+};
+
 // value only: xn[NX] = f(z[0..N))
 template <typename Dyn, typename real>
 __device__ __forceinline__ void dyn_value(const real (&z)[Dyn::NX + Dyn::NU], real h, real (&xn)[Dyn::NX]) {

@@ -613,7 +613,7 @@ __global__ __launch_bounds__(64) void k_dual(AuxArgs<real> a) {
 // (nx, nu) instances compiled into the library. Anything else is ALQP_E_UNSUPPORTED:
 // the product path fails loudly rather than falling back to a slow generic route.
 #define ALQP_FOR_EACH_DIMS(X) \
-    X(2, 1) X(4, 1) X(4, 2) X(6, 2) X(8, 2) X(10, 3) X(12, 4) X(13, 4) X(14, 4)
+    X(2, 1) X(4, 1) X(4, 2) X(6, 1) X(6, 2) X(8, 2) X(10, 3) X(12, 4) X(13, 4) X(14, 4)
 
 constexpr size_t kMaxLds = 160 * 1024;
 
@@ -700,6 +700,9 @@ int dispatch_solve_nonlin(int dyn_id, int nx, int nu, const SolveArgs<real> &a, 
                                               TraceArgs<real>{}, ws);
     if (dyn_id == DynCartpole1l<real>::ID && nx == 4 && nu == 1)
         return launch_quad_kernel<real, 4, 1>(k_solve_lin_quad<real, 4, 1, false, DynCartpole1l<real>>, a.B, stream, a,
+                                              TraceArgs<real>{}, ws);
+    if (dyn_id == DynCartpole2l<real>::ID && nx == 6 && nu == 1)
+        return launch_quad_kernel<real, 6, 1>(k_solve_lin_quad<real, 6, 1, false, DynCartpole2l<real>>, a.B, stream, a,
                                               TraceArgs<real>{}, ws);
     return ALQP_E_UNSUPPORTED;
 }
@@ -1086,6 +1089,53 @@ int dyn_cartpole1l_impl(long K, const void *x, const void *tau, double h, const 
     return hipGetLastError() == hipSuccess ? 0 : ALQP_E_LAUNCH;
 }
 
+// ---- dynamics provider: cartpole2l (model and dual-number step: alqp_dyn.hpp DynCartpole2l) -----
+template <typename real>
+__global__ __launch_bounds__(128) void k_dyn_cartpole2l(long K, const real *x, const real *tau, real h, const real *hpt,
+                                                        real *xn, real *J) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= K) return;
+    if (hpt) h = hpt[i];
+    if (J) {
+        Dual<real, 9> xd[6], td[3], on[6];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            xd[k] = dconst<real, 9>(x[6 * i + k]);
+            xd[k].d[k] = 1;
+        }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            td[k] = dconst<real, 9>(tau[3 * i + k]);
+            td[k].d[6 + k] = 1;
+        }
+        DynCartpole2l<real>::template step_full<9>(xd, td, h, on);
+#pragma unroll
+        for (int r = 0; r < 6; ++r) {
+            if (xn) xn[6 * i + r] = on[r].v;
+#pragma unroll
+            for (int c = 0; c < 9; ++c) J[54 * i + 9 * r + c] = on[r].d[c];
+        }
+    } else {
+        Dual<real, 0> xd[6], td[3], on[6];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) xd[k].v = x[6 * i + k];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) td[k].v = tau[3 * i + k];
+        DynCartpole2l<real>::template step_full<0>(xd, td, h, on);
+#pragma unroll
+        for (int r = 0; r < 6; ++r) xn[6 * i + r] = on[r].v;
+    }
+}
+
+template <typename real>
+int dyn_cartpole2l_impl(long K, const void *x, const void *tau, double h, const void *hpt, void *xn, void *J, void *stream) {
+    if (K < 0 || !x || !tau || (!xn && !J)) return ALQP_E_BADARG;
+    if (K == 0) return 0;
+    hipLaunchKernelGGL(k_dyn_cartpole2l<real>, dim3((unsigned)((K + 127) / 128)), dim3(128), 0, (hipStream_t)stream, K,
+                       (const real *)x, (const real *)tau, (real)h, (const real *)hpt, (real *)xn, (real *)J);
+    return hipGetLastError() == hipSuccess ? 0 : ALQP_E_LAUNCH;
+}
+
 // batch-global exit test of the Newton loop, taken on the device (al_utils.py:551-564)
 __global__ void k_exit_test(const double *sumsq, double *ctl, int mode, double tol) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
@@ -1123,6 +1173,13 @@ int alqp_dyn_cartpole1l_f32(long K, const void *x, const void *tau, double h, co
 }
 int alqp_dyn_cartpole1l_f64(long K, const void *x, const void *tau, double h, const void *h_pt, void *xnext, void *J, void *stream) {
     return alqp::dyn_cartpole1l_impl<double>(K, x, tau, h, h_pt, xnext, J, stream);
+}
+
+int alqp_dyn_cartpole2l_f32(long K, const void *x, const void *tau, double h, const void *h_pt, void *xnext, void *J, void *stream) {
+    return alqp::dyn_cartpole2l_impl<float>(K, x, tau, h, h_pt, xnext, J, stream);
+}
+int alqp_dyn_cartpole2l_f64(long K, const void *x, const void *tau, double h, const void *h_pt, void *xnext, void *J, void *stream) {
+    return alqp::dyn_cartpole2l_impl<double>(K, x, tau, h, h_pt, xnext, J, stream);
 }
 
 size_t alqp_workspace_bytes_nonlin(const AlqpDims *dims, int is_f64) {

@@ -96,3 +96,47 @@ class cartpole1l:
         be = default_backend()
         _, J = be.dyn_cartpole1l(torch.cat((q_in, qdot_in), 1).contiguous(), tau_in.contiguous(), h_in, want_jac=True)
         return [J[:, 2 * i:2 * i + 2, 2 * j:2 * j + 2].contiguous() for i in (0, 1) for j in (0, 1, 2)]
+
+
+class Cartpole2lDynamics:
+    """Two-link cartpole (`CartpoleDynamics(nx=6)`, my_envs/cartpole.py:30-32): x = (cart position,
+    th1, th2 relative to link 1, their rates), both angles 0 = upright; tau = (u, 0, 0)."""
+    nx, nu = 6, 1
+    fused_id = 3
+
+    def __init__(self, dt=0.05, backend=None):
+        self.dt = float(dt)
+        self.backend = backend
+
+    def _be(self):
+        if self.backend is None:
+            self.backend = default_backend()
+        return self.backend
+
+    @staticmethod
+    def _tau(u):
+        return torch.cat((u, torch.zeros_like(u), torch.zeros_like(u)), 1).contiguous()
+
+    def __call__(self, x, u):
+        xn, _ = self._be().dyn_cartpole2l(x.contiguous(), self._tau(u), self.dt, want_jac=False)
+        return xn
+
+    def jac(self, x, u):
+        xn, J = self._be().dyn_cartpole2l(x.contiguous(), self._tau(u), self.dt, want_jac=True)
+        return xn, (J[..., :6], J[..., 6:7])
+
+
+class cartpole2l:
+    """Module-shaped twin of the reference's compiled `cartpole2l` package (six [bsz, 3, 3] blocks)."""
+
+    @staticmethod
+    def dynamics(q_in, qdot_in, tau_in, h_in):
+        be = default_backend()
+        xn, _ = be.dyn_cartpole2l(torch.cat((q_in, qdot_in), 1).contiguous(), tau_in.contiguous(), h_in, want_jac=False)
+        return [xn[:, :3].contiguous(), xn[:, 3:].contiguous()]
+
+    @staticmethod
+    def derivatives(q_in, qdot_in, tau_in, h_in):
+        be = default_backend()
+        _, J = be.dyn_cartpole2l(torch.cat((q_in, qdot_in), 1).contiguous(), tau_in.contiguous(), h_in, want_jac=True)
+        return [J[:, 3 * i:3 * i + 3, 3 * j:3 * j + 3].contiguous() for i in (0, 1) for j in (0, 1, 2)]

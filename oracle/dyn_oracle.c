@@ -117,3 +117,75 @@ void dyn_cartpole1l_point(const double *q, const double *qd, const double *tau, 
 void dyn_cartpole1l(long K, const double *x, const double *tau, double h, double *xn, double *J) {
     for (long i = 0; i < K; ++i) dyn_cartpole1l_point(x + 4 * i, x + 4 * i + 2, tau + 2 * i, h, xn + 4 * i, J + 24 * i);
 }
+
+
+/* ---- cartpole2l ---------------------------------------------------------------------------
+ * deqmpc/my_envs/cartpole2l/src/generated_dynamics.c / generated_derivatives.c (the nx = 6 case
+ * of CartpoleDynamics, my_envs/cartpole.py:30-32): q = (cart x, th1, th2), th1 from upright, th2
+ * RELATIVE to link 1. Read as mathematics: one RK4 step of  M(q) q'' = tau - h(q, q') + G(q),
+ *   M = [[12, -(2 c1 + c12), -c12], [., 5 + 2 c2, 2 + c2], [., ., 2]]     (c1 = cos th1, c12 = cos(th1+th2), c2 = cos th2)
+ *   h = (2 s1 w1^2 + s12 (w1 + w2)^2,  -s2 w2 (2 w1 + w2),  s2 w1^2)       (Christoffel terms of M)
+ *   G = (0, 9.81 (2 s1 + s12), 9.81 s12)
+ * (cart 10 kg, two 1 kg links of length 1 with the masses at the tips... as identified from the
+ * compiled reference code: M^-1 from the response to tau at several poses, G from tau = 0, h from the
+ * mass matrix; pinned against its outputs, tests/golden/dyn_cartpole2l.npz).
+ */
+#define NT9 9
+typedef struct { double v, d[NT9]; } dual9;
+static dual9 c9(double v) { dual9 r; r.v = v; for (int i = 0; i < NT9; ++i) r.d[i] = 0; return r; }
+static dual9 a9(dual9 a, dual9 b) { dual9 r; r.v = a.v + b.v; for (int i = 0; i < NT9; ++i) r.d[i] = a.d[i] + b.d[i]; return r; }
+static dual9 s9(double s, dual9 a) { dual9 r; r.v = s * a.v; for (int i = 0; i < NT9; ++i) r.d[i] = s * a.d[i]; return r; }
+static dual9 m9(dual9 a, dual9 b) { dual9 r; r.v = a.v * b.v; for (int i = 0; i < NT9; ++i) r.d[i] = a.d[i] * b.v + a.v * b.d[i]; return r; }
+static dual9 sin9(dual9 a) { dual9 r; double c = cos(a.v); r.v = sin(a.v); for (int i = 0; i < NT9; ++i) r.d[i] = c * a.d[i]; return r; }
+static dual9 cos9(dual9 a) { dual9 r; double s = -sin(a.v); r.v = cos(a.v); for (int i = 0; i < NT9; ++i) r.d[i] = s * a.d[i]; return r; }
+static dual9 inv9(dual9 a) { dual9 r; r.v = 1.0 / a.v; for (int i = 0; i < NT9; ++i) r.d[i] = -a.d[i] * r.v * r.v; return r; }
+
+static void cart2_acc(const dual9 *q, const dual9 *w, const dual9 *tau, dual9 *acc) {
+    dual9 s1 = sin9(q[1]), c1 = cos9(q[1]), s2 = sin9(q[2]), c2 = cos9(q[2]);
+    dual9 t12 = a9(q[1], q[2]), s12 = sin9(t12), c12 = cos9(t12);
+    dual9 m11 = c9(12.0), m12 = s9(-1.0, a9(s9(2.0, c1), c12)), m13 = s9(-1.0, c12);
+    dual9 m22 = a9(c9(5.0), s9(2.0, c2)), m23 = a9(c9(2.0), c2), m33 = c9(2.0);
+    dual9 w12 = a9(w[1], w[2]);
+    dual9 r0 = a9(tau[0], s9(-1.0, a9(s9(2.0, m9(s1, m9(w[1], w[1]))), m9(s12, m9(w12, w12)))));
+    dual9 r1 = a9(a9(tau[1], m9(s2, m9(w[2], a9(s9(2.0, w[1]), w[2])))), s9(9.81, a9(s9(2.0, s1), s12)));
+    dual9 r2 = a9(a9(tau[2], s9(-1.0, m9(s2, m9(w[1], w[1])))), s9(9.81, s12));
+    /* symmetric 3x3 solve by cofactors */
+    dual9 A00 = a9(m9(m22, m33), s9(-1.0, m9(m23, m23)));
+    dual9 A01 = a9(m9(m13, m23), s9(-1.0, m9(m12, m33)));
+    dual9 A02 = a9(m9(m12, m23), s9(-1.0, m9(m13, m22)));
+    dual9 A11 = a9(m9(m11, m33), s9(-1.0, m9(m13, m13)));
+    dual9 A12 = a9(m9(m12, m13), s9(-1.0, m9(m11, m23)));
+    dual9 A22 = a9(m9(m11, m22), s9(-1.0, m9(m12, m12)));
+    dual9 idet = inv9(a9(a9(m9(m11, A00), m9(m12, A01)), m9(m13, A02)));
+    acc[0] = m9(idet, a9(a9(m9(A00, r0), m9(A01, r1)), m9(A02, r2)));
+    acc[1] = m9(idet, a9(a9(m9(A01, r0), m9(A11, r1)), m9(A12, r2)));
+    acc[2] = m9(idet, a9(a9(m9(A02, r0), m9(A12, r1)), m9(A22, r2)));
+}
+
+/* one point: x[6] = (q, qd), tau[3] -> xn[6], J[6][9] = d xn / d(q, qd, tau) */
+void dyn_cartpole2l_point(const double *x, const double *tau, double h, double *xn, double *J) {
+    dual9 q[3], w[3], ta[3], k1q[3], k1w[3], k2q[3], k2w[3], k3q[3], k3w[3], k4q[3], k4w[3], tq[3], tw[3];
+    for (int i = 0; i < 3; ++i) {
+        q[i] = c9(x[i]); q[i].d[i] = 1;
+        w[i] = c9(x[3 + i]); w[i].d[3 + i] = 1;
+        ta[i] = c9(tau[i]); ta[i].d[6 + i] = 1;
+    }
+    for (int i = 0; i < 3; ++i) k1q[i] = w[i];
+    cart2_acc(q, w, ta, k1w);
+    for (int i = 0; i < 3; ++i) { tq[i] = a9(q[i], s9(0.5 * h, k1q[i])); tw[i] = a9(w[i], s9(0.5 * h, k1w[i])); k2q[i] = tw[i]; }
+    cart2_acc(tq, tw, ta, k2w);
+    for (int i = 0; i < 3; ++i) { tq[i] = a9(q[i], s9(0.5 * h, k2q[i])); tw[i] = a9(w[i], s9(0.5 * h, k2w[i])); k3q[i] = tw[i]; }
+    cart2_acc(tq, tw, ta, k3w);
+    for (int i = 0; i < 3; ++i) { tq[i] = a9(q[i], s9(h, k3q[i])); tw[i] = a9(w[i], s9(h, k3w[i])); k4q[i] = tw[i]; }
+    cart2_acc(tq, tw, ta, k4w);
+    for (int i = 0; i < 3; ++i) {
+        dual9 oq = a9(q[i], s9(h / 6.0, a9(a9(k1q[i], s9(2.0, k2q[i])), a9(s9(2.0, k3q[i]), k4q[i]))));
+        dual9 ow = a9(w[i], s9(h / 6.0, a9(a9(k1w[i], s9(2.0, k2w[i])), a9(s9(2.0, k3w[i]), k4w[i]))));
+        xn[i] = oq.v; xn[3 + i] = ow.v;
+        for (int j = 0; j < 9; ++j) { J[9 * i + j] = oq.d[j]; J[9 * (3 + i) + j] = ow.d[j]; }
+    }
+}
+
+void dyn_cartpole2l(long K, const double *x, const double *tau, double h, double *xn, double *J) {
+    for (long i = 0; i < K; ++i) dyn_cartpole2l_point(x + 6 * i, tau + 3 * i, h, xn + 6 * i, J + 54 * i);
+}

@@ -18,12 +18,13 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = os.path.join(_HERE, "libdyn_oracle.so")
 _REF = os.path.join(_HERE, "_ref", "libpendulum1l_casadi.so")
 _REF_CP = os.path.join(_HERE, "_ref", "libcartpole1l_casadi.so")
+_REF_CP2 = os.path.join(_HERE, "_ref", "libcartpole2l_casadi.so")
 
 
 def build():
     if not os.path.exists(_LIB) or os.path.getmtime(_LIB) < os.path.getmtime(os.path.join(_HERE, "dyn_oracle.c")):
         subprocess.check_call(["make", "-C", _HERE, "-B", "libdyn_oracle.so"], stdout=subprocess.DEVNULL)
-    if os.path.isdir("/root/reference/deqmpc/my_envs/pendulum1l/src") and not (os.path.exists(_REF) and os.path.exists(_REF_CP)):
+    if os.path.isdir("/root/reference/deqmpc/my_envs/pendulum1l/src") and not (os.path.exists(_REF) and os.path.exists(_REF_CP) and os.path.exists(_REF_CP2)):
         subprocess.check_call(["make", "-C", _HERE, "ref"], stdout=subprocess.DEVNULL)
     return _LIB
 
@@ -116,4 +117,47 @@ def cartpole1l_ref(x, tau, h):
         blk = [np.array(list(b)).reshape(2, 2, order="F") for b in o6]
         J[i, :2, 0:2], J[i, :2, 2:4], J[i, :2, 4:6] = blk[0], blk[1], blk[2]
         J[i, 2:, 0:2], J[i, 2:, 2:4], J[i, 2:, 4:6] = blk[3], blk[4], blk[5]
+    return xn, J
+
+
+def cartpole2l(x, tau, h):
+    """x [K,6] = (cart x, th1, th2 (relative), rates), tau [K,3] -> xn [K,6], J [K,6,9]."""
+    build()
+    lib = C.CDLL(_LIB)
+    x = np.ascontiguousarray(x, np.float64)
+    tau = np.ascontiguousarray(tau, np.float64)
+    K = x.shape[0]
+    xn, J = np.empty((K, 6)), np.empty((K, 6, 9))
+    P = lambda a: a.ctypes.data_as(C.c_void_p)
+    lib.dyn_cartpole2l.argtypes = [C.c_long, C.c_void_p, C.c_void_p, C.c_double, C.c_void_p, C.c_void_p]
+    lib.dyn_cartpole2l(K, P(x), P(tau), float(h), P(xn), P(J))
+    return xn, J
+
+
+def have_ref_cartpole2():
+    return os.path.exists(_REF_CP2)
+
+
+def cartpole2l_ref(x, tau, h):
+    """The same through the reference's generated code (six 3x3 blocks, column-major)."""
+    lib = C.CDLL(_REF_CP2)
+    x = np.ascontiguousarray(x, np.float64)
+    tau = np.ascontiguousarray(tau, np.float64)
+    K = x.shape[0]
+    xn, J = np.empty((K, 6)), np.empty((K, 6, 9))
+    dbl = C.c_double
+    iw = (C.c_longlong * 256)()
+    w = (dbl * 16384)()
+    for i in range(K):
+        ins = [(dbl * 3)(*x[i, :3]), (dbl * 3)(*x[i, 3:]), (dbl * 3)(*tau[i]), (dbl * 1)(h)]
+        arg = (C.POINTER(dbl) * 4)(*[C.cast(a, C.POINTER(dbl)) for a in ins])
+        o2 = [(dbl * 3)(), (dbl * 3)()]
+        lib.eval_forward_dynamics(arg, (C.POINTER(dbl) * 2)(*[C.cast(a, C.POINTER(dbl)) for a in o2]), iw, w, 0)
+        xn[i] = list(o2[0]) + list(o2[1])
+        o6 = [(dbl * 9)() for _ in range(6)]
+        lib.eval_forward_derivatives(arg, (C.POINTER(dbl) * 6)(*[C.cast(a, C.POINTER(dbl)) for a in o6]), iw, w, 0)
+        blk = [np.array(list(b)).reshape(3, 3, order="F") for b in o6]
+        for bi in range(2):
+            for bj in range(3):
+                J[i, 3 * bi:3 * bi + 3, 3 * bj:3 * bj + 3] = blk[3 * bi + bj]
     return xn, J

@@ -11,6 +11,7 @@ from oracle import dyn_py
 
 GOLD = np.load(os.path.join(os.path.dirname(__file__), "golden", "dyn_pendulum1l.npz"))
 GOLDC = np.load(os.path.join(os.path.dirname(__file__), "golden", "dyn_cartpole1l.npz"))
+GOLDC2 = np.load(os.path.join(os.path.dirname(__file__), "golden", "dyn_cartpole2l.npz"))
 
 
 @pytest.mark.parametrize("tag", ["h05", "h01"])
@@ -206,15 +207,15 @@ def test_hip_cartpole_class_and_package_twin():
 
 # ---- nonlinear fused solve (alqp_solve_nonlin) ----------------------------------------------
 @pytest.mark.gpu
-@pytest.mark.parametrize("env", ["pendulum1l", "cartpole1l"])
+@pytest.mark.parametrize("env", ["pendulum1l", "cartpole1l", "cartpole2l"])
 @pytest.mark.parametrize("dtype,tol", [(torch.float64, 5e-7), (torch.float32, 2e-3)])
 def test_fused_nonlinear_solve_equals_the_launch_per_step_path(env, dtype, tol):
     """One launch with the model inlined against the host-driven nonlinear-caller mode (kernel per
     Newton-step phase, provider kernels for dx / dx_jac - the path that is validated against the
     reference's nonlinear goldens), both with exit_mode='fixed'. Active bounds included."""
-    from deq_mpc_corl_amd import MPC, QuadCost, Pendulum1lDynamics, Cartpole1lDynamics
+    from deq_mpc_corl_amd import MPC, QuadCost, Pendulum1lDynamics, Cartpole1lDynamics, Cartpole2lDynamics
     dev = "cuda:0"
-    prov = Pendulum1lDynamics(0.05) if env == "pendulum1l" else Cartpole1lDynamics(0.05)
+    prov = {"pendulum1l": Pendulum1lDynamics, "cartpole1l": Cartpole1lDynamics, "cartpole2l": Cartpole2lDynamics}[env](0.05)
     nx, T, B = prov.nx, (6 if env == "pendulum1l" else 9), 70
     n = nx + 1
     g = torch.Generator().manual_seed(11)
@@ -396,3 +397,53 @@ def test_fused_nonlinear_solve_does_not_depend_on_workspace_contents(dtype):
         for a, b in zip(outs[0], other):
             assert torch.equal(a, b)
     assert bool(torch.isfinite(outs[0][0]).all())
+
+
+# ---- cartpole2l ------------------------------------------------------------------------------
+@pytest.mark.parametrize("tag", ["h05", "h01"])
+def test_cartpole2l_restatement_matches_reference_vectors(tag):
+    xn, J = dyn_py.cartpole2l(GOLDC2["x"], GOLDC2["tau"], float(GOLDC2[tag + "_h"]))
+    assert np.abs(xn - GOLDC2[tag + "_xn"]).max() < 5e-14
+    assert np.abs(J - GOLDC2[tag + "_J"]).max() < 2e-14
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype,tol", [(torch.float64, 2e-12), (torch.float32, 2e-4)])
+@pytest.mark.parametrize("tag", ["h05", "h01"])
+def test_hip_cartpole2l_matches_reference_vectors(dtype, tol, tag):
+    from deq_mpc_corl_amd.backend import default_backend
+    be = default_backend()
+    dev = "cuda:0"
+    x = torch.tensor(GOLDC2["x"], dtype=dtype, device=dev)
+    tau = torch.tensor(GOLDC2["tau"], dtype=dtype, device=dev)
+    xn, J = be.dyn_cartpole2l(x, tau, float(GOLDC2[tag + "_h"]))
+    xo, _ = be.dyn_cartpole2l(x, tau, float(GOLDC2[tag + "_h"]), want_jac=False)
+    torch.cuda.synchronize()
+    scale = 1.0 + np.abs(GOLDC2[tag + "_xn"])
+    assert (np.abs(xn.cpu().numpy() - GOLDC2[tag + "_xn"]) / scale).max() < tol
+    assert (np.abs(J.cpu().numpy() - GOLDC2[tag + "_J"]) / (1.0 + np.abs(GOLDC2[tag + "_J"]))).max() < tol
+    assert torch.allclose(xo, xn, rtol=0, atol=1e-12 if dtype == torch.float64 else 1e-5)
+
+
+@pytest.mark.gpu
+def test_hip_cartpole2l_class_and_package_twin():
+    from deq_mpc_corl_amd import Cartpole2lDynamics
+    from deq_mpc_corl_amd.dynamics import cartpole2l
+    dev, dt = "cuda:0", torch.float64
+    sel = (GOLDC2["tau"][:, 1] == 0) & (GOLDC2["tau"][:, 2] == 0)
+    x = torch.tensor(GOLDC2["x"][sel], dtype=dt, device=dev)
+    u = torch.tensor(GOLDC2["tau"][sel][:, :1], dtype=dt, device=dev)
+    dyn = Cartpole2lDynamics(dt=0.05)
+    xn, (A, B) = dyn.jac(x, u)
+    assert A.shape == (x.shape[0], 6, 6) and B.shape == (x.shape[0], 6, 1)
+    assert np.abs(xn.cpu().numpy() - GOLDC2["h05_xn"][sel]).max() < 2e-12
+    assert np.abs(A.cpu().numpy() - GOLDC2["h05_J"][sel][:, :, :6]).max() < 2e-12
+    assert np.abs(B.cpu().numpy() - GOLDC2["h05_J"][sel][:, :, 6:7]).max() < 2e-12
+    xa = torch.tensor(GOLDC2["x"], dtype=dt, device=dev)
+    ta = torch.tensor(GOLDC2["tau"], dtype=dt, device=dev)
+    h = torch.full((xa.shape[0], 1), 0.05, dtype=dt, device=dev)
+    qn, qdn = cartpole2l.dynamics(xa[:, :3].contiguous(), xa[:, 3:].contiguous(), ta, h)
+    assert np.abs(torch.cat((qn, qdn), 1).cpu().numpy() - GOLDC2["h05_xn"]).max() < 2e-12
+    blocks = cartpole2l.derivatives(xa[:, :3].contiguous(), xa[:, 3:].contiguous(), ta, h)
+    assert len(blocks) == 6 and all(b.shape == (xa.shape[0], 3, 3) for b in blocks)
+    assert np.abs(blocks[5].cpu().numpy() - GOLDC2["h05_J"][:, 3:, 6:9]).max() < 2e-12   # dqdot'/dtau
