@@ -118,7 +118,7 @@ class MPC(Module):
                  detach_unconverged=True, backprop=True, slew_rate_penalty=None,
                  solver_type="dense", add_goal_constraint=False, x_goal=None, diag_cost=True,
                  ineqG=None, ineqh=None, state_estimator=False, dtype=torch.float64,
-                 exit_mode="reference", backend=None, process_group=None):
+                 exit_mode="reference", backend=None, process_group=None, prefer_fused=False):
         super().__init__()
         if (u_lower is None) != (u_upper is None) or u_lower is None:
             raise ValueError("MPC: u_lower and u_upper are both required (AL_mpc.py:145,152)")
@@ -148,6 +148,7 @@ class MPC(Module):
         self.rho_max = 1e8
         self.dyn_res_prev = 1000000
         self.exit_mode = exit_mode
+        self.prefer_fused = bool(prefer_fused)  # take the compiled-in dynamics model even where it is not the default
         self.process_group = process_group
         self._backend = backend
         self.warm_starting = None  # set by reinitialize(); forward() insists on it
@@ -512,6 +513,7 @@ class MPC(Module):
             F_last = F
         elif (F is None and not stream and self.exit_mode == "fixed"
               and getattr(st.dx, "fused_id", None) is not None and hasattr(be, "solve_nonlin")
+              and (getattr(st.dx, "fused_default", True) or self.prefer_fused)
               and (getattr(st.dx, "nx", None), getattr(st.dx, "nu", None)) == (nx, nu)):
             # ---- nonlinear dynamics whose model is compiled into the library (dynamics.py): the
             # whole nonlinear solve in ONE launch, no PyTorch round trip between Newton steps
@@ -536,6 +538,7 @@ class MPC(Module):
                 prev_mean = float(ws["rn2"].sqrt().mean().item())
             fused_nl = (F is None and not stream and self.exit_mode == "reference"
                         and getattr(st.dx, "fused_id", None) is not None and hasattr(be, "solve_nonlin")
+                        and (getattr(st.dx, "fused_default", True) or self.prefer_fused)
                         and (getattr(st.dx, "nx", None), getattr(st.dx, "nu", None)) == (nx, nu))
             for _ in range(num_iters):
                 rho_last = st.rho.clone()

@@ -234,7 +234,7 @@ def test_fused_nonlinear_solve_equals_the_launch_per_step_path(env, dtype, tol):
 
     res = {}
     for name, dyn in (("fused", prov), ("stepwise", Plain())):
-        mpc = MPC(nx, 1, T, u_lower=-ub, u_upper=ub, n_batch=B, dtype=dtype, exit_mode="fixed")
+        mpc = MPC(nx, 1, T, u_lower=-ub, u_upper=ub, n_batch=B, dtype=dtype, exit_mode="fixed", prefer_fused=True)
         mpc.reinitialize(x0, None)
         mpc.al_iter = 3
         cost = QuadCost(torch.diag_embed(Qd), q, torch.zeros(B, T, dtype=dtype, device=dev))

@@ -268,7 +268,7 @@ def test_headline_size_properties():
 
 
 @pytest.mark.parametrize("variant", ["team", "quad"])
-@pytest.mark.parametrize("nx,nu", [(2, 1), (4, 1), (4, 2), (6, 2), (8, 2), (10, 3), (12, 4), (13, 4), (14, 4)])
+@pytest.mark.parametrize("nx,nu", [(2, 1), (4, 1), (4, 2), (6, 1), (6, 2), (8, 2), (10, 3), (12, 4), (13, 4), (14, 4)])
 @pytest.mark.parametrize("dtype", ["f32", "f64"])
 def test_every_compiled_dims_vs_oracle(nx, nu, dtype, variant):
     """Every (nx,nu) instance in the library, ragged batch (B not a multiple of the

@@ -4,7 +4,7 @@ written in PyTorch (autograd Jacobians), pendulum1l (B=4096, T=5) and cartpole1l
 import json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
-from deq_mpc_corl_amd import MPC, QuadCost, Pendulum1lDynamics, Cartpole1lDynamics
+from deq_mpc_corl_amd import MPC, QuadCost, Pendulum1lDynamics, Cartpole1lDynamics, Cartpole2lDynamics
 
 dev, dt = "cuda:0", torch.float64
 h = 0.05
@@ -34,6 +34,23 @@ def cart_torch(x, u):
     return torch.cat((qn, vn), 1)
 
 
+def cart2_torch(x, u):
+    def acc(q, v, t):
+        t1, t2, w1, w2 = q[:, 1], q[:, 2], v[:, 1], v[:, 2]
+        s1, c1, s2, c2 = torch.sin(t1), torch.cos(t1), torch.sin(t2), torch.cos(t2)
+        s12, c12 = torch.sin(t1 + t2), torch.cos(t1 + t2)
+        one = torch.ones_like(t1)
+        M = torch.stack([torch.stack([12 * one, -(2 * c1 + c12), -c12], 1),
+                         torch.stack([-(2 * c1 + c12), 5 + 2 * c2, 2 + c2], 1),
+                         torch.stack([-c12, 2 + c2, 2 * one], 1)], 1)
+        r = torch.stack([t[:, 0] - (2 * s1 * w1 ** 2 + s12 * (w1 + w2) ** 2),
+                         s2 * w2 * (2 * w1 + w2) + 9.81 * (2 * s1 + s12),
+                         -s2 * w1 ** 2 + 9.81 * s12], 1)
+        return torch.linalg.solve(M, r.unsqueeze(-1)).squeeze(-1)
+    qn, vn = rk4(acc, x[:, :3], x[:, 3:], u)
+    return torch.cat((qn, vn), 1)
+
+
 def autograd_jac(f, nx):
     def jac(x, u):
         with torch.enable_grad():
@@ -46,7 +63,8 @@ def autograd_jac(f, nx):
 
 out = []
 for name, nx, T, B, prov, ft in (("pendulum1l", 2, 5, 4096, Pendulum1lDynamics(h), pend_torch),
-                                 ("cartpole1l", 4, 10, 4096, Cartpole1lDynamics(h), cart_torch)):
+                                 ("cartpole1l", 4, 10, 4096, Cartpole1lDynamics(h), cart_torch),
+                                 ("cartpole2l", 6, 10, 4096, Cartpole2lDynamics(h), cart2_torch)):
     g = torch.Generator().manual_seed(1)
     x0 = (0.3 * torch.randn(B, nx, generator=g)).to(dt).to(dev)
     n = nx + 1
@@ -69,7 +87,7 @@ for name, nx, T, B, prov, ft in (("pendulum1l", 2, 5, 4096, Pendulum1lDynamics(h
                                  ("model inlined: ONE launch (alqp_solve_nonlin), fixed 4 steps", prov, prov.jac, "fixed")):
         ts = []
         for rep in range(4):
-            mpc = MPC(nx, 1, T, u_lower=-5.0, u_upper=5.0, n_batch=B, dtype=dt, exit_mode=mode)
+            mpc = MPC(nx, 1, T, u_lower=-5.0, u_upper=5.0, n_batch=B, dtype=dt, exit_mode=mode, prefer_fused=True)
             mpc.reinitialize(x0, None)
             mpc.al_iter = 2
             torch.cuda.synchronize(); t0 = time.perf_counter()
