@@ -50,6 +50,25 @@ for dt, name, sz in ((torch.float64, "f64", 8), (torch.float32, "f32", 4)):
     r = {"kernel": "k_dyn_cartpole1l", "dtype": name, "points": K, "ms": ms, "points_per_s": K / ms * 1e3,
          "GB_per_s": nbytes / ms / 1e6, "hbm_frac_of_8TBs": nbytes / ms / 1e6 / 8000.0}
     print(json.dumps(r)); out.append(r)
+for dt, name, sz in ((torch.float64, "f64", 8), (torch.float32, "f32", 4)):
+    K = 16384 * 19 * 8
+    x = torch.randn(K, 6, dtype=dt, device=dev)
+    tau = torch.randn(K, 3, dtype=dt, device=dev)
+    for _ in range(3):
+        be.dyn_cartpole2l(x, tau, 0.05)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    reps = 10
+    for _ in range(reps):
+        be.dyn_cartpole2l(x, tau, 0.05)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    nbytes = K * (6 + 3 + 6 + 54) * sz
+    r = {"kernel": "k_dyn_cartpole2l", "dtype": name, "points": K, "ms": ms, "points_per_s": K / ms * 1e3,
+         "GB_per_s": nbytes / ms / 1e6, "hbm_frac_of_8TBs": nbytes / ms / 1e6 / 8000.0}
+    print(json.dumps(r)); out.append(r)
 # C oracle (one thread) on a bounded sample
 from oracle import dyn_py
 xs, us = np.random.randn(200000, 2), np.random.randn(200000, 1)
