@@ -8,21 +8,24 @@
 // entirely in registers (rows dealt cyclically, row i on lane i % 4) and every
 // cross-lane operand is a DPP quad broadcast (a VALU operand modifier, no LDS, no
 // v_readlane): ~6x fewer wave instructions per solve. The price: the per-stage factor
-// (lower triangle of L_tt, ~1 KB) and the vectors y/d, r, s are streamed through an
-// HBM workspace, written in the forward sweep and read back in the backward sweep /
-// line search. MI355X's 8 TB/s HBM is otherwise idle on this problem (the team variant
-// moves 0.05 TB/s), so spending bandwidth to buy lane utilisation is the right trade.
+// and the step vectors are streamed through an HBM workspace, written in the forward
+// sweep and read back in the backward sweep. MI355X's 8 TB/s HBM is otherwise idle on this
+// problem, so spending bandwidth to buy lane utilisation is the right trade once the batch
+// fills the chip (B >= 4096; below that the team variant has the lower latency).
 //
-// Workspace discipline: every word of the workspace is only ever read by the lane that
-// wrote it (same-thread RAW through global memory needs no fence).
+// Workspace record of one (instance, stage) (QCfg): the unscaled root-free factor
+// (Hh[k][j] = Lh[k][j] p_j, 1/p_j on the diagonal), y/d, r, s, and the stage's slice of
+// z, lam, diag Q, q, c and the bounds: everything a sweep needs apart from F_t sits in a
+// few whole 128-byte lines. stage_in() copies the slices in, iter_end() copies z, lam out.
 //
-// Forward stage t (right-looking panel factorisation, all loops fully unrolled):
-//   rows of H_tt (slot s, lane q: row 4s+q), rows of -rho F_t, the replicated rhs row;
-//   pivot j: broadcast pivot, v_rsq, scale column j, rank-1 update of the trailing
-//   columns (one DPP broadcast of L[k][j] per (j,k) pair), and the Schur complement
-//   W_t W_t' / W_t y_t for stage t+1 accumulated in the same pass.
-// Backward stage t: d_t = L^{-T} ( y_t + rho L^{-1} F_t' dx_{t+1} ) by substitution on
-//   replicated vectors, s_t = dx_{t+1} - F_t d_t.
+// One Newton step = forward sweep (applies the pending line-search step, residual,
+// gradient, H_tt, right-looking LDL' panel, Schur complement for the next stage) +
+// backward sweep (substitutions, s_t = (J d)_t, and in fp32 the merits of the 20
+// line-search candidates accumulated on the fly). One AL iteration ends with iter_end():
+// apply, dual update, next starting merit, ||r+||^2, copy-out in ONE pass.
+// With a dynamics model compiled in (alqp_dyn.hpp) the same sweeps run on linearisations
+// made on the device (linearize) and the line search / dual update use the true dynamics
+// (merit_nonlin, iter_end<Dyn>): the nonlinear MPC solve in one launch.
 #pragma once
 #include <hip/hip_runtime.h>
 
