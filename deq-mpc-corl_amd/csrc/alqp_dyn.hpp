@@ -244,4 +244,25 @@ __device__ __forceinline__ void dyn_value_jac(const real (&z)[Dyn::NX + Dyn::NU]
     }
 }
 
+// value and THIS LANE's share of the Jacobian: the four lanes of a quad split the n tangents,
+// lane q carries columns k = 4 i + q (i < NTL): Jl[r][i] = d f_r / d z_{4i+q} (zero past n)
+template <typename Dyn, typename real>
+__device__ __forceinline__ void dyn_value_jac_split(const real (&z)[Dyn::NX + Dyn::NU], real h, int q, real (&xn)[Dyn::NX],
+                                                    real (&Jl)[Dyn::NX][(Dyn::NX + Dyn::NU + 3) / 4]) {
+    constexpr int N = Dyn::NX + Dyn::NU, NTL = (N + 3) / 4;
+    Dual<real, NTL> zd[N], xd[Dyn::NX];
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+        zd[j] = dconst<real, NTL>(z[j]);
+        zd[j].d[j >> 2] = ((j & 3) == q) ? real(1) : real(0);
+    }
+    Dyn::template step<NTL>(zd, h, xd);
+#pragma unroll
+    for (int i = 0; i < Dyn::NX; ++i) {
+        xn[i] = xd[i].v;
+#pragma unroll
+        for (int j = 0; j < NTL; ++j) Jl[i][j] = xd[i].d[j];
+    }
+}
+
 }  // namespace alqp

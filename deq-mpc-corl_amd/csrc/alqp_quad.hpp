@@ -285,7 +285,7 @@ struct Quad {
     // ---- nonlinear fused solve (a dynamics model Dyn is inlined, alqp_dyn.hpp) -----------------
     // Linearisation pass of a Newton step (al_utils.py:233-248, dx_jac at the current iterate):
     // applies the pending line-search step, then per stage x+ = f(z_t) and J = df/dz by dual
-    // numbers (every lane of the quad evaluates the model: it is tiny next to the factorisation),
+    // numbers (the value in every lane, the n tangents split over the quad's four lanes),
     // F_t = J -> the workspace, c_t = f(z_t) - J z_t and r_t = x_{t+1} - f(z_t) -> the record. The
     // sweeps then run unchanged on (F_t, c_t).
     template <class Dyn>
@@ -332,17 +332,21 @@ struct Quad {
                 }
             }
             if (dyn) {
-                real xn[NX], J[NX][N];
-                dyn_value_jac<Dyn, real>(zt, dyn_h, xn, J);
+                // the quad's lanes split the n tangents (lane q: columns 4i+q), then row 4s+q of J is
+                // gathered: column k comes from lane k%4, the row index differs per destination lane
+                constexpr int NTL = (N + 3) / 4;
+                real xn[NX], Jl[NX][NTL];
+                dyn_value_jac_split<Dyn, real>(zt, dyn_h, q, xn, Jl);
 #pragma unroll
                 for (int s = 0; s < SW; ++s) {
                     const int r = 4 * s + q;
                     real Jr[N];
 #pragma unroll
                     for (int k = 0; k < N; ++k)
-                        Jr[k] = sel4(J[4 * s][k], (4 * s + 1 < NX) ? J[(4 * s + 1 < NX) ? 4 * s + 1 : 0][k] : real(0),
-                                     (4 * s + 2 < NX) ? J[(4 * s + 2 < NX) ? 4 * s + 2 : 0][k] : real(0),
-                                     (4 * s + 3 < NX) ? J[(4 * s + 3 < NX) ? 4 * s + 3 : 0][k] : real(0), q);
+                        Jr[k] = sel4(qbv(Jl[4 * s][k >> 2], k),
+                                     (4 * s + 1 < NX) ? qbv(Jl[(4 * s + 1 < NX) ? 4 * s + 1 : 0][k >> 2], k) : real(0),
+                                     (4 * s + 2 < NX) ? qbv(Jl[(4 * s + 2 < NX) ? 4 * s + 2 : 0][k >> 2], k) : real(0),
+                                     (4 * s + 3 < NX) ? qbv(Jl[(4 * s + 3 < NX) ? 4 * s + 3 : 0][k >> 2], k) : real(0), q);
                     const real xr = sel4(xn[4 * s], (4 * s + 1 < NX) ? xn[(4 * s + 1 < NX) ? 4 * s + 1 : 0] : real(0),
                                          (4 * s + 2 < NX) ? xn[(4 * s + 2 < NX) ? 4 * s + 2 : 0] : real(0),
                                          (4 * s + 3 < NX) ? xn[(4 * s + 3 < NX) ? 4 * s + 3 : 0] : real(0), q);

@@ -103,9 +103,9 @@ class Cartpole2lDynamics:
     th1, th2 relative to link 1, their rates), both angles 0 = upright; tau = (u, 0, 0)."""
     nx, nu = 6, 1
     fused_id = 3
-    # The model is compiled into the nonlinear fused solve as well, but every lane of a quad evaluates
-    # it in full there; for this heavier model at B = 4096 the launch-per-phase route (one thread per
-    # point) is faster (3.2 ms against 4.3 ms per call), so the MPC only fuses on request
+    # The model is compiled into the nonlinear fused solve as well; for this heavier model at B = 4096
+    # it only ties with the launch-per-phase route (3.2 ms per call both; the line search costs five
+    # full model evaluations per lane and stage), so the MPC only fuses on request
     fused_default = False
 
     def __init__(self, dt=0.05, backend=None):
