@@ -223,3 +223,56 @@ def test_streaming_mode_matches_cpu_host_logic():
     assert torch.allclose(h[0], cc[0], atol=1e-6) and torch.allclose(h[1], cc[1], atol=1e-6)
     assert torch.allclose(h[3], cc[3], atol=1e-5) and torch.allclose(h[4], cc[4], atol=1e-5)
     assert torch.equal(h[6], cc[6])
+
+
+def test_bad_arguments_fail_loudly():
+    """Error behaviour of the boundary: unsupported sizes, missing workspace, wrong line-search length
+    for the nonlinear solve, CPU tensors and dtype mismatches raise; nothing falls back silently."""
+    from deq_mpc_corl_amd import synthetic_problem
+    from deq_mpc_corl_amd.backend import default_backend
+    be = default_backend()
+    dt = torch.float64
+    p = synthetic_problem(8, 5, 8, 2, seed=1, dtype=dt, device=DEV)
+    with pytest.raises(RuntimeError):                      # (5, 3) is not an instantiated size
+        q = synthetic_problem(8, 5, 5, 3, seed=1, dtype=dt, device=DEV)
+        solve(q, dt, "quad")
+    assert not be.supported(8, 5, 5, 3, dt) and be.supported(8, 5, 8, 2, dt)
+    with pytest.raises(ValueError):                        # explicit workspace too small
+        be.solve_lin((8, 5, 8, 2), p.Qd, p.q, p.F, p.c, p.x0, p.u_lo, p.u_hi, 0, 0, p.z0.clone(),
+                     torch.zeros(8, 5 * 8 + 2 * 5 * 2, dtype=dt, device=DEV), torch.ones(8, dtype=dt, device=DEV),
+                     torch.zeros(8, dtype=dt, device=DEV), variant="quad", workspace=torch.zeros(16, dtype=dt, device=DEV))
+    with pytest.raises(RuntimeError):                      # CPU tensor
+        be.solve_lin((8, 5, 8, 2), p.Qd.cpu(), p.q, p.F, p.c, p.x0, p.u_lo, p.u_hi, 0, 0, p.z0.clone(),
+                     torch.zeros(8, 60, dtype=dt, device=DEV), torch.ones(8, dtype=dt, device=DEV),
+                     torch.zeros(8, dtype=dt, device=DEV))
+    with pytest.raises(TypeError):                         # dtype mismatch
+        be.solve_lin((8, 5, 8, 2), p.Qd.float(), p.q, p.F, p.c, p.x0, p.u_lo, p.u_hi, 0, 0, p.z0.clone(),
+                     torch.zeros(8, 60, dtype=dt, device=DEV), torch.ones(8, dtype=dt, device=DEV),
+                     torch.zeros(8, dtype=dt, device=DEV))
+    with pytest.raises(RuntimeError):                      # model id / size mismatch in the nonlinear solve
+        be.solve_nonlin((8, 5, 8, 2), 1, 0.05, p.Qd, p.q, p.x0, p.u_lo, p.u_hi, 0, 0, p.z0.clone(),
+                        torch.zeros(8, 60, dtype=dt, device=DEV), torch.ones(8, dtype=dt, device=DEV),
+                        torch.zeros(8, dtype=dt, device=DEV))
+
+
+def test_exit_test_kernel_matches_the_rule():
+    """alqp_exit_test: mode 0 initialises {done, steps, old}; mode 1 counts a step and applies
+    new < tol or |old - new| / new < tol (al_utils.py:560-564); once done it is inert."""
+    from deq_mpc_corl_amd.backend import default_backend
+    be = default_backend()
+    ctl = torch.full((3,), 7.0, dtype=torch.float64, device=DEV)
+    s = lambda v: torch.tensor([v], dtype=torch.float64, device=DEV)
+    be.exit_test(s(4.0), ctl, 0)
+    assert ctl.tolist() == [0.0, 0.0, 2.0]
+    be.exit_test(s(1.0), ctl, 1)                           # 2 -> 1: keeps going
+    assert ctl.tolist() == [0.0, 1.0, 1.0]
+    be.exit_test(s(1.0 * (1 + 1e-4) ** 2), ctl, 1)         # relative change 1e-4 < 1e-3: done
+    assert ctl[0].item() == 1.0 and ctl[1].item() == 2.0
+    be.exit_test(s(100.0), ctl, 1)                         # inert afterwards
+    assert ctl[1].item() == 2.0
+    be.exit_test(s(1e-8), ctl, 0)
+    be.exit_test(s(1e-8), ctl, 1)                          # new = 1e-4 < 1e-3: done after one step
+    assert ctl[0].item() == 1.0 and ctl[1].item() == 1.0
+    be.exit_test(s(float("nan")), ctl, 0)
+    be.exit_test(s(float("nan")), ctl, 1)                  # NaN compares false: keeps going (as torch does)
+    assert ctl[0].item() == 0.0 and ctl[1].item() == 1.0
