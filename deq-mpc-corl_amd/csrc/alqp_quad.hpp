@@ -143,6 +143,7 @@ struct QCfg {
     // fp32: the starting merit comes out of the first forward sweep; fp64 is short of registers
     // (it would spill 0.7 KB more) and keeps the residual pre-pass + a merit pass
     static constexpr bool PHI0_FWD = sizeof(real) == 4;
+    static constexpr bool S_AFTER = sizeof(real) == 8;  // fp64: Schur accumulation after the panel (register pressure)
     __host__ __device__ static constexpr int p4(int x) { return (x + 3) & ~3; }
     // The record also carries the stage's slice of every small per-stage array (working copies
     // of z and lam, copies of diag Q, q, c and the bounds): in their own arrays these are 52-68
@@ -612,6 +613,7 @@ struct Quad {
             // pivots and Lh unit lower. Column j is kept UNSCALED (Hh[k][j] = Lh[k][j] p_j) and
             // 1/p_j takes the pivot's place: no square root, no column scaling, and the solves
             // below use Hh[k][j] * (x_j / p_j).
+            real ipv[C::S_AFTER ? N : 1];
 #pragma unroll
             for (int j = 0; j < N; ++j) {
                 const real p = qbv(H[C::hidx(j >> 2, j)], j);
@@ -626,7 +628,8 @@ struct Quad {
                     for (int s = 0; s < SW; ++s) W[s][k] = fma_(-W[s][j], lkj, W[s][k]);
                     Y[k] = fma_(-Y[j], lkj, Y[k]);
                 }
-                if (dyn) {
+                if constexpr (C::S_AFTER) ipv[j] = ip;
+                if (!C::S_AFTER && dyn) {
 #pragma unroll
                     for (int b = 0; b < NX; ++b) {
                         const real wbj = qbv(W[b >> 2][j], b) * ip;
@@ -659,6 +662,23 @@ struct Quad {
                 }
             }
         
+            if constexpr (C::S_AFTER) {
+                // fp64: the Schur complement of this stage once the factor's registers are free
+                if (dyn) {
+#pragma unroll
+                    for (int j = 0; j < N; ++j) {
+#pragma unroll
+                        for (int b = 0; b < NX; ++b) {
+                            const real wbj = qbv(W[b >> 2][j], b) * ipv[j];
+#pragma unroll
+                            for (int s = (b >> 2); s < SW; ++s) S[C::hidx(s, b)] = fma_(W[s][j], wbj, S[C::hidx(s, b)]);
+                        }
+                        const real yip = Y[j] * ipv[j];
+#pragma unroll
+                        for (int s = 0; s < SW; ++s) Sy[s] = fma_(W[s][j], yip, Sy[s]);
+                    }
+                }
+            }
             // ---- carry to the next stage: replicated v = lam + rho r and W_t y_t
 #pragma unroll
             for (int j = 0; j < NX; ++j) {
