@@ -482,8 +482,18 @@ struct Quad {
                 real cs[SW], zn[SW], lm[SW];
                 real lu[NU], ll[NU], bu[NU], bl[NU];
                 gload<N>(rp + C::oZ, zt);
-                gload<N>(rp + C::oQ, Qt);
-                gload<N>(rp + C::oq, qt);
+                real Qo[SY], qo[SY];  // fp64: own elements only, broadcast where used (48 registers less)
+                if constexpr (C::S_AFTER) {
+#pragma unroll
+                    for (int m = 0; m < SY; ++m) {
+                        const int jc = (4 * m + q < N) ? 4 * m + q : N - 1;
+                        Qo[m] = rp[C::oQ + jc];
+                        qo[m] = rp[C::oq + jc];
+                    }
+                } else {
+                    gload<N>(rp + C::oQ, Qt);
+                    gload<N>(rp + C::oq, qt);
+                }
                 const int td = dyn ? t : (T > 1 ? T - 2 : 0);  // valid addresses for the last stage
                 load_F_rows(td, W);
                 const real *rn = recp(td + 1);
@@ -537,9 +547,11 @@ struct Quad {
                 // ---- gradient (replicated in the 4 lanes) and diagonal of H_tt
 #pragma unroll
                 for (int j = 0; j < N; ++j) {
-                    real g = fma_(Qt[j], zt[j], qt[j]);
-                    real d = Qt[j];
-                    if constexpr (C::PHI0_FWD) mrep = fma_(fma_(real(0.5) * Qt[j], zt[j], qt[j]), zt[j], mrep);
+                    const real Qj = C::S_AFTER ? qbv(Qo[j >> 2], j) : Qt[j];
+                    const real qj = C::S_AFTER ? qbv(qo[j >> 2], j) : qt[j];
+                    real g = fma_(Qj, zt[j], qj);
+                    real d = Qj;
+                    if constexpr (C::PHI0_FWD) mrep = fma_(fma_(real(0.5) * Qj, zt[j], qj), zt[j], mrep);
                     if (j < NX) {
                         g += vprev[j];
                         d += rho;
