@@ -62,9 +62,9 @@ def autograd_jac(f, nx):
 
 
 out = []
-for name, nx, T, B, prov, ft in (("pendulum1l", 2, 5, 4096, Pendulum1lDynamics(h), pend_torch),
-                                 ("cartpole1l", 4, 10, 4096, Cartpole1lDynamics(h), cart_torch),
-                                 ("cartpole2l", 6, 10, 4096, Cartpole2lDynamics(h), cart2_torch)):
+for name, nx, T, B, prov, ft in (("pendulum1l", 2, 5, int(os.environ.get("NL_B", "4096")), Pendulum1lDynamics(h), pend_torch),
+                                 ("cartpole1l", 4, 10, int(os.environ.get("NL_B", "4096")), Cartpole1lDynamics(h), cart_torch),
+                                 ("cartpole2l", 6, 10, int(os.environ.get("NL_B", "4096")), Cartpole2lDynamics(h), cart2_torch)):
     g = torch.Generator().manual_seed(1)
     x0 = (0.3 * torch.randn(B, nx, generator=g)).to(dt).to(dev)
     n = nx + 1
