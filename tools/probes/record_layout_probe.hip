@@ -5,6 +5,8 @@
 // six, contiguous, like the factor's slot of the record).
 //   layout 0 "per instance":  word w of record (i, t) at ((i*T + t)*RECW + w): a wave-wide
 //                             instruction touches 16 pieces 28 KB apart (what ships today);
+//   layout 2 "stage-major":   record (i, t) at ((t*B + i)*RECW): the 16 records a wave touches in a
+//                             stage are one contiguous 22.5 KB block;
 //   layout 1 "interleaved":   the 16 instances of a wave interleaved at 64-byte granularity:
 //                             a wave-wide instruction touches 1 KB of contiguous memory.
 // Prints GB/s (bytes read + written over the event time) for both.
@@ -29,6 +31,7 @@ __global__ __launch_bounds__(64) void walk(float *ws, int B, int passes, float *
 #pragma unroll
             for (int c = 0; c < PIECES; ++c) {
                 const size_t w = LAYOUT == 0 ? (i * T + t) * RECW + 16 * c + 4 * q
+                               : LAYOUT == 2 ? ((size_t)t * B + i) * RECW + 16 * c + 4 * q
                                              : ((wave * T + t) * PIECES + c) * 256 + iq * 16 + 4 * q;
                 v[c] = *reinterpret_cast<const float4 *>(ws + w);
             }
@@ -37,6 +40,7 @@ __global__ __launch_bounds__(64) void walk(float *ws, int B, int passes, float *
                 acc += v[c].x + v[c].y + v[c].z + v[c].w;
                 if ((WR == 1 && (c & 3) == 0) || (WR == 2 && c < 6)) {
                     const size_t w = LAYOUT == 0 ? (i * T + t) * RECW + 16 * c + 4 * q
+                                   : LAYOUT == 2 ? ((size_t)t * B + i) * RECW + 16 * c + 4 * q
                                                  : ((wave * T + t) * PIECES + c) * 256 + iq * 16 + 4 * q;
                     float4 o = v[c];
                     o.x += 1.0f;
@@ -75,7 +79,8 @@ int main(int argc, char **argv) {
     printf("B=%d T=%d RECW=%d (%.0f MB per pass), %d passes\n", B, T, RECW, words * 4 / 1e6, passes);
     printf("read only : per-instance %.0f GB/s   interleaved %.0f GB/s\n", run<0, 0>(ws, B, passes, sink), run<1, 0>(ws, B, passes, sink));
     printf("read + write every 4th piece : per-instance %.0f GB/s   interleaved %.0f GB/s\n", run<0, 1>(ws, B, passes, sink), run<1, 1>(ws, B, passes, sink));
-    printf("read + write pieces 0..5     : per-instance %.0f GB/s   interleaved %.0f GB/s\n", run<0, 2>(ws, B, passes, sink), run<1, 2>(ws, B, passes, sink));
+    printf("read + write pieces 0..5     : per-instance %.0f GB/s   interleaved %.0f GB/s   stage-major %.0f GB/s\n", run<0, 2>(ws, B, passes, sink), run<1, 2>(ws, B, passes, sink), run<2, 2>(ws, B, passes, sink));
+    printf("read only                    : stage-major %.0f GB/s\n", run<2, 0>(ws, B, passes, sink));
     CK(hipFree(ws));
     CK(hipFree(sink));
     return 0;
