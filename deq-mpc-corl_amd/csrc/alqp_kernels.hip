@@ -201,7 +201,7 @@ __global__ __launch_bounds__(64, 2) void k_solve_lin(SolveArgs<real> a, TraceArg
             a.rho[b] = tm.rho;
             a.phi[b] = phi_prev;
             if (a.rnorm2) a.rnorm2[b] = rn2;
-            if (a.info) a.info[b] = tm.info;
+            if (a.info && tm.info && a.info[b] == 0) a.info[b] = tm.info;  // sticky: first failure of the solve
             if (a.status) a.status[b] = bad ? 0 : 1;
         }
     }
@@ -365,7 +365,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
         a.rho[b] = qd.rho;
         a.phi[b] = phi_prev;
         if (a.rnorm2) a.rnorm2[b] = rn2;
-        if (a.info) a.info[b] = qd.info;
+        if (a.info && qd.info && a.info[b] == 0) a.info[b] = qd.info;  // sticky: first failure of the solve
         if (a.status) a.status[b] = bad ? 0 : 1;
     }
 }
@@ -449,7 +449,7 @@ __global__ __launch_bounds__(64) void k_newton_step(StepArgs<real> a) {
             real *gf = a.factor + (size_t)b * T * C::XT;
             for (int e = li; e < T * C::XT; e += G) gf[e] = tm.Xp[e];
         }
-        if (li == 0 && a.info) a.info[b] = tm.info;
+        if (li == 0 && a.info && tm.info && a.info[b] == 0) a.info[b] = tm.info;
     }
 }
 

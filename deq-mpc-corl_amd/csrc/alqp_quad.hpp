@@ -630,7 +630,11 @@ struct Quad {
             for (int j = 0; j < N; ++j) {
                 const real p = qbv(H[C::hidx(j >> 2, j)], j);
                 if (!(p > 0) && info == 0) info = t * N + j + 1;
-                const real ip = rcp_(p);
+                // |p| (a free source modifier): on a non-positive pivot - rounding at rho*cond beyond the
+                // dtype, flagged in info - the panel becomes a modified Cholesky (factor of H + E, E >= 0)
+                // and the step stays a descent direction for the line search to judge; the reference's
+                // half-finished cholesky_ex factor (al_utils.py:510-515) has nothing to restate
+                const real ip = rcp_(fabs_(p));
 #pragma unroll
                 for (int k = j + 1; k < N; ++k) {
                     const real lkj = qbv(H[C::hidx(k >> 2, j)], k) * ip;

@@ -423,7 +423,7 @@ struct Team {
                 if (!(p > 0) && info == 0) info = t * N + j + 1;
                 // no masking needed: H rows above the diagonal hold unused garbage, identity
                 // rows stay exactly 0 left of their diagonal (X is upper triangular)
-                l[j] = acc * rsqrt_(p);
+                l[j] = acc * rsqrt_(fabs_(p));  // |p|: modified Cholesky on a non-positive pivot (flagged in info)
             }
             // ---- stage results
             if (isW || isY) {

@@ -318,6 +318,28 @@ class MPC(Module):
             torch.distributed.all_reduce(s, group=self.process_group)
         return math.sqrt(float(s.item()))
 
+    def _sharded(self):
+        return self.process_group is not None or (
+            torch.distributed.is_available() and torch.distributed.is_initialized()
+            and getattr(self, "sync_global_exit", False))
+
+    def _global_mean(self, v):
+        """Batch mean of a per-instance quantity (the stream loop's break test,
+        `dyn_res_clamp.mean().item()`, AL_mpc.py:406-408); over ALL ranks of a sharded batch, so
+        that every rank leaves the loop in the same iteration."""
+        s = torch.stack((v.sum(dtype=torch.float64), torch.tensor(float(v.numel()), dtype=torch.float64, device=v.device)))
+        if self._sharded():
+            torch.distributed.all_reduce(s, group=self.process_group)
+        s = s.tolist()
+        return s[0] / s[1]
+
+    def _global_max(self, v):
+        """`rho.max().item()` (AL_mpc.py:412, 420), over all ranks of a sharded batch."""
+        m = v.max().to(torch.float64).reshape(1)
+        if self._sharded():
+            torch.distributed.all_reduce(m, op=torch.distributed.ReduceOp.MAX, group=self.process_group)
+        return float(m.item())
+
     def _al_solve(self, x, u, dx, dx_jac, x0, Qd, q, stream_mode):
         B = x.shape[0]
         dt = self.dtype
@@ -403,6 +425,19 @@ class MPC(Module):
             be.exit_test(self._global_sumsq(ws["rn2"]), ctl, 1)
         return ctl
 
+    def _linearize(self, st, z):
+        """dx_jac at every (x_t, u_t), t < T-1 -> (f(z) [B,T-1,nx], F = [A|B] [B,T-1,nx,n]).
+        Called the way the reference does (al_utils.py:501-503, 233-248): grad mode on and the
+        iterate requiring grad, because the torch-coded environments differentiate through their own
+        RK4 step inside `dx_jac` (rex_quadrotor.py:136-144)."""
+        B, T, nx, nu = z.shape[0], self.T, self.n_state, self.n_ctrl
+        with torch.enable_grad():
+            zz = z.detach().requires_grad_(True)
+            xn_j, (A, Bm) = st.dx_jac(zz[:, :-1, :nx].reshape(-1, nx), zz[:, :-1, nx:].reshape(-1, nu))
+        F = torch.cat((A.detach().reshape(B, T - 1, nx, nx), Bm.detach().reshape(B, T - 1, nx, nu)),
+                      dim=-1).to(z.dtype).contiguous()
+        return xn_j.detach().reshape(B, T - 1, nx).to(z.dtype).contiguous(), F
+
     def _newton_al_nonlin(self, st, Qd, q, bnd, ws, need_factor):
         """NewtonAL.forward (al_utils.py:451-576) with `dx`/`dx_jac` as PyTorch calls
         between kernel launches."""
@@ -426,9 +461,7 @@ class MPC(Module):
         steps = 0
         while steps < MAX_NEWTON:
             steps += 1
-            xn_j, (A, Bm) = st.dx_jac(z[:, :-1, :nx].reshape(-1, nx), z[:, :-1, nx:].reshape(-1, nu))
-            F = torch.cat((A.reshape(B, T - 1, nx, nx), Bm.reshape(B, T - 1, nx, nu)), dim=-1).to(dt).contiguous()
-            xn = xn_j.reshape(B, T - 1, nx).to(dt).contiguous()
+            xn, F = self._linearize(st, z)
             be.newton_step(dims, z, xn, F, st.x0, st.lam, st.rho, Qd, q, lo, hi, sb, stt, ws["d"],
                            factor=ws.get("factor") if need_factor else None, info=ws["info"])
             if need_factor:
@@ -465,13 +498,24 @@ class MPC(Module):
               "info": torch.zeros(B, dtype=torch.int32, device=dev),
               "status": torch.ones(B, dtype=torch.uint8, device=dev)}
         lin = st.lin
+        if need_grad and self.linearize_once and st.stream_mode:
+            # al_utils_lin.NewtonAL.backward returns 14 gradients for 15 inputs (al_utils_lin.py:444-459):
+            # autograd rejects it, so the reference cannot differentiate this route. Same error type.
+            raise RuntimeError("MPC: the linearize_once streaming route is not differentiable (the reference's "
+                               "al_utils_lin.NewtonAL.backward returns an incorrect number of gradients)")
         use_qws = need_grad and hasattr(be, "backward_ws") and B >= getattr(be, "QUAD_MIN_BATCH", 0) and (
-            lin is not None or (bool(self.linearize_once) and st.stream_mode))
+            lin is not None)
         if use_qws:
             ws["qws"] = be.new_workspace(dims, st.z)
         elif need_grad:
             ws["factor"] = torch.empty(B, T, n * (n + 1) // 2, dtype=dt, device=dev)
         stream = st.stream_mode
+        if self.linearize_once and not stream:
+            # The reference cannot run this combination either: al_solve (AL_mpc.py:292-306) hands the
+            # frozen-linearisation dict to al_utils.merit_grad_hessian, which calls it
+            # ("TypeError: 'dict' object is not callable", al_utils.py:237). Same error type here.
+            raise TypeError("MPC: linearize_once is only defined for the streaming route (after "
+                            "warm_start_initialize); the reference's al_solve raises TypeError on it as well")
         linearize_once = bool(self.linearize_once) and stream
         npa = []
         rho_last = None
@@ -494,9 +538,9 @@ class MPC(Module):
             c = lin[1].detach().to(device=dev, dtype=dt).contiguous()
         elif linearize_once:
             # frozen linearisation captured once per call (al_utils_lin.py:140-169)
+            # note the offset: x_{t+1} of the WARM START minus F_t z_t, not f(z_t) - F_t z_t (:154)
             z = st.z
-            _, (A, Bm) = st.dx_jac(z[:, :-1, :nx].reshape(-1, nx), z[:, :-1, nx:].reshape(-1, nu))
-            F = torch.cat((A.reshape(B, T - 1, nx, nx), Bm.reshape(B, T - 1, nx, nu)), dim=-1).to(dt).contiguous()
+            _, F = self._linearize(st, z)
             c = (z[:, 1:, :nx] - torch.einsum("btij,btj->bti", F, z[:, :-1])).contiguous()
 
         # ---- fast path: the whole solve in ONE launch -----------------------------------
@@ -535,7 +579,7 @@ class MPC(Module):
                 xn = true_next(st.z)
                 be.merit(dims, 1, st.z, xn, st.x0, st.lam, st.rho, Qd, q, lo, hi, sb, stt,
                          ws["phi"], ws["rn2"])
-                prev_mean = float(ws["rn2"].sqrt().mean().item())
+                prev_mean = self._global_mean(ws["rn2"].sqrt())
             fused_nl = (F is None and not stream and self.exit_mode == "reference"
                         and getattr(st.dx, "fused_id", None) is not None and hasattr(be, "solve_nonlin")
                         and (getattr(st.dx, "fused_default", True) or self.prefer_fused)
@@ -580,13 +624,13 @@ class MPC(Module):
                     ws["primed"] = None   # lam/rho changed behind the workspace records' back
                 if stream:
                     if linearize_once:
-                        mean = float(ws["rn2"].sqrt().mean().item())
+                        mean = self._global_mean(ws["rn2"].sqrt())
                         if prev_mean is not None and not mean < prev_mean:
                             break
                         prev_mean = mean
-                    if float(st.rho.max().item()) > self.rho_max:
+                    if self._global_max(st.rho) > self.rho_max:
                         break
-            if stream and float(st.rho.max().item()) > self.rho_max:
+            if stream and self._global_max(st.rho) > self.rho_max:
                 st.status_flag = True
         # device-side exit counters (one read-back for the whole solve)
         if any(torch.is_tensor(v) for v in npa):

@@ -146,7 +146,13 @@ static void FN(grad_hess_one)(int T, int nx, int nu, const REAL *z, const REAL *
 /* ---- block-tridiagonal Cholesky (the algorithm the HIP kernel implements) -- */
 
 /* In-place lower Cholesky of an n x n block; returns index+1 of the first
- * non-positive pivot (0 = ok), like cholesky_ex's info. */
+ * non-positive pivot (0 = ok), like cholesky_ex's info.
+ * Failure policy ("non-positive pivots"): the reference's cholesky_ex stops at
+ * such a pivot and its cholesky_solve then uses the half-finished factor (al_utils.py:510-515; the
+ * linalg.solve fallback only fires on NaN/Inf, :517) - an undefined direction that only the line
+ * search's strict-decrease test guards. There is nothing to restate; the kernels and this oracle
+ * take |p| for a non-positive pivot p (a modified Cholesky: the factor of H + E, E >= 0 diagonal),
+ * report the instance in info[] and leave the guarding to the same line search. */
 static int FN(chol_block)(int n, REAL *A)
 {
     int info = 0;
@@ -154,7 +160,7 @@ static int FN(chol_block)(int n, REAL *A)
         REAL d = A[j * n + j];
         for (int k = 0; k < j; ++k) d -= A[j * n + k] * A[j * n + k];
         if (!(d > 0) && !info) info = j + 1;
-        REAL l = SQRT(d);
+        REAL l = SQRT(d < 0 ? -d : d);
         A[j * n + j] = l;
         for (int i = j + 1; i < n; ++i) {
             REAL s = A[i * n + j];

@@ -11,7 +11,7 @@ def load(name):
     d = dict(np.load(os.path.join(GOLDEN, name + ".npz")))
     for k in ("B", "T", "nx", "nu", "al_iter", "nonlinear", "active", "seed", "status",
               "n_steps_recorded", "calls"):
-        if k in d:
+        if k in d and np.ndim(d[k]) == 0:
             d[k] = int(d[k])
     if "dtype" in d:
         d["dtype"] = str(d["dtype"])
@@ -21,7 +21,8 @@ def load(name):
 def names(pattern="*"):
     # dyn_*.npz and *casadi* belong to the dynamics-provider tests (tests/test_dynamics_provider.py)
     return sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, pattern + ".npz"))
-                  if not os.path.basename(p).startswith("dyn_") and "casadi" not in os.path.basename(p))
+                  if not os.path.basename(p).startswith("dyn_") and "casadi" not in os.path.basename(p)
+                  and "stream" not in os.path.basename(p) and not os.path.basename(p).startswith(("ip_", "obs_")))
 
 
 def step_context(g):

@@ -61,19 +61,21 @@ class OracleBackend:
             return (np.einsum("btij,btj->bti", F_, v[:, :-1]) + c_).astype(npdt)
 
         L = None
+        inf_acc = np.zeros(B, np.int32)
         for _ in range(al_iter):
             if flags & INIT_MERIT:
                 ph, _ = orc.merit(s, zz, xnext(zz), x0_, ll, rr, Qd_, q_, lo, hi)
             for _ in range(max_newton):
                 g, Hd, Hs = orc.grad_hess(s, zz, xnext(zz), F_, x0_, ll, rr, Qd_, q_, lo, hi)
-                d, _, L, _ = orc.newton_dir(s, g, Hd, Hs, nx, want_factor=True)
+                d, inf, L, _ = orc.newton_dir(s, g, Hd, Hs, nx, want_factor=True)
+                inf_acc = np.where(inf_acc == 0, inf, inf_acc)
                 phis = []
                 for k in range(n_ls):
                     zc = (zz + npdt(2.0 ** -k) * d).astype(npdt)
                     phis.append(orc.merit(s, zc, xnext(zc), x0_, ll, rr, Qd_, q_, lo, hi)[0])
                 kk, acc, pm = orc.linesearch_pick(s, np.stack(phis), ph)
                 alpha = np.where(acc > 0, 2.0 ** -kk.astype(np.float64), 0.0).astype(npdt)
-                zz = (zz + alpha[:, None, None] * d).astype(npdt)
+                zz = np.where((acc > 0)[:, None, None], zz + alpha[:, None, None] * d, zz).astype(npdt)
                 ph = pm
             if flags & DUAL_UPDATE:
                 ll, rr = orc.dual_update(s, zz, xnext(zz), x0_, lo, hi, ll, rr)
@@ -84,8 +86,9 @@ class OracleBackend:
         phi.copy_(torch.from_numpy(ph))
         if rnorm2 is not None:
             rnorm2.copy_(torch.from_numpy(rp2))
-        if info is not None:
-            info.zero_()
+        if info is not None:   # sticky like the kernels: the first failure of the solve stays
+            cur = _n(info)
+            info.copy_(torch.from_numpy(np.where(cur == 0, inf_acc, cur).astype(np.int32)))
         if status is not None:
             status.copy_(torch.from_numpy(np.isfinite(zz).all(axis=(1, 2)).astype(np.uint8)))
         if factor is not None and (flags & SAVE_FACTOR) and L is not None:
@@ -126,7 +129,8 @@ class OracleBackend:
         if factor is not None:
             factor.copy_(torch.from_numpy(self._pack_X(L)))
         if info is not None:
-            info.copy_(torch.from_numpy(inf))
+            cur = _n(info)
+            info.copy_(torch.from_numpy(np.where(cur == 0, inf, cur).astype(np.int32)))
 
     def merit(self, dims, K, zc, xnext, x0, lam, rho, Qd, q, ulo, uhi, sb_u, st_u, phi, rnorm2=None):
         B, T, nx, nu = dims
@@ -143,7 +147,7 @@ class OracleBackend:
         s = _sfx(z)
         kk, acc, pm = orc.linesearch_pick(s, _n(phi), _n(phi_prev))
         alpha = torch.from_numpy(np.where(acc > 0, 2.0 ** -kk.astype(np.float64), 0.0)).to(z.dtype)
-        z.add_(alpha[:, None, None] * d)
+        z.copy_(torch.where(torch.from_numpy(acc > 0)[:, None, None], z + alpha[:, None, None] * d, z))
         phi_prev.copy_(torch.from_numpy(pm))
         if k_out is not None:
             k_out.copy_(torch.from_numpy(kk))
