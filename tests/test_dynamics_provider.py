@@ -279,9 +279,9 @@ def test_host_logic_with_restated_dynamics_vs_reference_mpc(name):
 
         def jac(self, x, u):
             if name.startswith("pend"):
-                xn, A, Bm = dyn_py.pendulum1l(x.numpy(), u.numpy(), 0.05)
+                xn, A, Bm = dyn_py.pendulum1l(x.detach().numpy(), u.detach().numpy(), 0.05)
             else:
-                xn, J = dyn_py.cartpole1l(x.numpy(), np.concatenate([u.numpy(), np.zeros((u.shape[0], 1))], 1), 0.05)
+                xn, J = dyn_py.cartpole1l(x.detach().numpy(), np.concatenate([u.detach().numpy(), np.zeros((u.shape[0], 1))], 1), 0.05)
                 A, Bm = J[:, :, :4].copy(), J[:, :, 4:5].copy()
             return torch.from_numpy(xn), (torch.from_numpy(A), torch.from_numpy(Bm))
 
