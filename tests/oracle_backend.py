@@ -169,3 +169,28 @@ class OracleBackend:
         qg, Qg = orc.backward(s, L, _n(F), _n(rho), _n(z_final), _n(gbar))
         q_grad.copy_(torch.from_numpy(qg))
         Qd_grad.copy_(torch.from_numpy(Qg))
+
+
+    # ---- interior-point path (oracle/ipm_oracle.c): CPU twin of HipBackend.ipm_solve / ipm_backward ----
+    def ipm_solve(self, dims, Cd, c, F, f, x0, uhi, ulo, exit_mode="reference", eps=1e-12, not_improved_lim=3,
+                  max_iter=20, ry_fn=None):
+        from oracle import ipm_py
+        B, T, nx, nu = dims
+        s = _sfx(c)
+        tm = lambda a: np.ascontiguousarray(np.swapaxes(_n(a), 0, 1))   # time-major -> batch-major
+        cb = None
+        if ry_fn is not None:
+            cb = lambda x: _n(ry_fn(torch.from_numpy(x).to(c.dtype)))
+        o = ipm_py.forward(s, tm(Cd), tm(c), tm(F), tm(f), _n(x0), _n(uhi), _n(ulo), solver=0,
+                           exit_mode=0 if exit_mode == "reference" else 1, eps=eps,
+                           not_improved_lim=not_improved_lim, max_iter=max_iter, ry_fn=cb)
+        out = {k: torch.from_numpy(o[k]) for k in ("zhat", "nus", "lams", "slacks", "resid", "info")}
+        out["iters"] = o["iters"]
+        return out
+
+    def ipm_backward(self, dims, Cd, F, lams, slacks, g):
+        from oracle import ipm_py
+        s = _sfx(g)
+        tm = lambda a: np.ascontiguousarray(np.swapaxes(_n(a), 0, 1))
+        dx, dlam, dnu = ipm_py.backward(s, tm(Cd), tm(F), _n(lams), _n(slacks), _n(g), solver=0)
+        return torch.from_numpy(dx), torch.from_numpy(dlam), torch.from_numpy(dnu)
