@@ -13,7 +13,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libmi_alqp.so")
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 
 class AlqpDims(C.Structure):
@@ -31,6 +31,11 @@ class AlqpTrace(C.Structure):
                 ("phi_prev", C.c_void_p), ("k", C.c_void_p), ("accept", C.c_void_p)]
 
 
+class AlqpIpmParams(C.Structure):
+    _fields_ = [("flags", C.c_int), ("max_iter", C.c_int), ("iter0", C.c_int), ("kkt_eps", C.c_double)]
+
+
+ALQP_IPM_INIT, ALQP_IPM_RESID, ALQP_IPM_STEP, ALQP_IPM_LOOP, ALQP_IPM_FINAL = 1, 2, 4, 8, 16
 ALQP_INIT_MERIT = 1
 ALQP_DUAL_UPDATE = 2
 ALQP_SAVE_FACTOR = 4
@@ -60,6 +65,11 @@ _SIGS = {
                                    C.c_double, _P]),
     "alqp_backward": (C.c_int, [C.POINTER(AlqpDims), _P, _P, _P, _P, _P, _P, _P, _P]),
     "alqp_backward_ws": (C.c_int, [C.POINTER(AlqpDims), _P, C.c_size_t, _P, _P, _P, _P, _P, _P, _P]),
+    "alqp_ipm_solve": (C.c_int, [C.POINTER(AlqpDims), C.POINTER(AlqpIpmParams), _P, _P, _P, _P, _P, _P, _P,
+                                 C.c_long, C.c_long, C.c_long, C.c_long, C.c_long, C.c_long, _P, C.c_size_t, _P,
+                                 _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "alqp_ipm_backward": (C.c_int, [C.POINTER(AlqpDims), _P, _P, C.c_long, C.c_long, C.c_long, C.c_long, _P, _P, _P,
+                                    _P, C.c_size_t, _P, _P, _P, _P, _P]),
 }
 _PLAIN = {
     "alqp_abi_version": (C.c_int, []),
@@ -69,6 +79,7 @@ _PLAIN = {
     "alqp_workspace_bytes": (C.c_size_t, [C.POINTER(AlqpDims), C.c_int]),
     "alqp_exit_test": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_void_p]),
     "alqp_workspace_bytes_nonlin": (C.c_size_t, [C.POINTER(AlqpDims), C.c_int]),
+    "alqp_ipm_workspace_bytes": (C.c_size_t, [C.POINTER(AlqpDims), C.c_int]),
 }
 
 EXPORTED_SYMBOLS = sorted([f"{n}_{s}" for n in _SIGS for s in ("f32", "f64")] + list(_PLAIN))

@@ -306,6 +306,93 @@ class HipBackend:
         _lib.check(rc, "alqp_backward_ws_" + sfx)
 
 
+    # ---- interior-point path (csrc/alqp_ipm.hip) -------------------------------------------------
+    def _ipm_ws(self, dims, like):
+        d = _lib.AlqpDims(*dims)
+        need = int(self.lib.alqp_ipm_workspace_bytes(C.byref(d), int(like.dtype == torch.float64)))
+        if need == 0:
+            raise RuntimeError(f"mi_alqp: no interior-point kernel instance for (nx={dims[2]}, nu={dims[3]})")
+        key = ("ipm", like.device, like.dtype)
+        ws = self._ws.get(key)
+        if ws is None or ws.numel() * ws.element_size() < need:
+            ws = torch.empty(need // like.element_size() + 16, dtype=like.dtype, device=like.device)
+            self._ws[key] = ws
+        return ws, need
+
+    def ipm_solve(self, dims, Cd, c, F, f, x0, uhi, ulo, exit_mode="reference", eps=1e-12, not_improved_lim=3,
+                  max_iter=20, ry_fn=None, kkt_eps=1e-7):
+        """pdipm_b_LU.forward (batch_LU.py:29-197) on time-major data: Cd, c [T,B,n]; F [T-1,B,nx,n];
+        f [T-1,B,nx]; x0 [B,nx]; uhi, ulo [nu]. ry_fn(z [B,T*n]) -> [B,T*nx]: equality residual of the TRUE
+        dynamics (one launch per iteration, PyTorch call in between), or None for A z - b.
+        exit_mode "fixed" (and no ry_fn): ONE launch for the whole solve. "reference": the reference's
+        batch-global exit rule, one host read per iteration (the reference syncs there as well)."""
+        B, T, nx, nu = dims
+        n = nx + nu
+        dt, dev = c.dtype, c.device
+        sfx = _dt(c)
+        d = _lib.AlqpDims(B, T, nx, nu)
+        ws, need = self._ipm_ws(dims, c)
+        out = {"zhat": torch.empty(B, T * n, dtype=dt, device=dev), "nus": torch.empty(B, T * nx, dtype=dt, device=dev),
+               "lams": torch.empty(B, 2 * T * nu, dtype=dt, device=dev),
+               "slacks": torch.empty(B, 2 * T * nu, dtype=dt, device=dev),
+               "resid": torch.empty(B, dtype=dt, device=dev), "info": torch.zeros(B, dtype=torch.int32, device=dev)}
+        mu = torch.empty(B, dtype=dt, device=dev)
+        improved = torch.zeros(B, dtype=torch.int32, device=dev)
+        fn = getattr(self.lib, "alqp_ipm_solve_" + sfx)
+        ptrs = (_ptr(Cd, "Cd", dt), _ptr(c, "c", dt), _ptr(F, "F", dt), _ptr(f, "f", dt), _ptr(x0, "x0", dt),
+                _ptr(uhi, "u_upper", dt), _ptr(ulo, "u_lower", dt), B * n, n, B * nx * n, nx * n, B * nx, nx)
+
+        def launch(flags, iters=0, it0=0, ry=None):
+            p = _lib.AlqpIpmParams(flags, iters, it0, kkt_eps)
+            rc = fn(C.byref(d), C.byref(p), *ptrs, _ptr(ws, "workspace", dt), need, _ptr(ry, "ry", dt, True),
+                    _ptr(out["zhat"], "zhat", dt), _ptr(out["nus"], "nus", dt), _ptr(out["lams"], "lams", dt),
+                    _ptr(out["slacks"], "slacks", dt), _ptr(out["resid"], "resid", dt), _ptr(mu, "mu", dt), None,
+                    _ptr(improved, "improved", torch.int32), _ptr(out["info"], "info", torch.int32), _stream())
+            _lib.check(rc, "alqp_ipm_solve_" + sfx)
+
+        if exit_mode == "fixed" and ry_fn is None:
+            launch(_lib.ALQP_IPM_INIT | _lib.ALQP_IPM_LOOP | _lib.ALQP_IPM_FINAL, max_iter)
+            out["iters"] = max_iter
+            return out
+        launch(_lib.ALQP_IPM_INIT)
+        ws_words = need // c.element_size() // B
+        cur_x = ws[:B * ws_words].view(B, ws_words)[:, :T * n]      # the iterate's x block of every instance
+        n_not_improved, done = 0, max_iter
+        for it in range(max_iter):
+            ry = ry_fn(cur_x.contiguous()).to(dt).contiguous() if ry_fn is not None else None
+            launch(_lib.ALQP_IPM_RESID, 0, it, ry)
+            if exit_mode == "reference":
+                # batch_LU.py:120-151: nNotImproved counts iterations in which NO instance improved
+                any_imp, best_max, mu_min = torch.stack((improved.max().to(torch.float64), out["resid"].max().to(torch.float64),
+                                                         mu.min().to(torch.float64))).tolist()
+                n_not_improved = 0 if (it == 0 or any_imp > 0) else n_not_improved + 1
+                if n_not_improved == not_improved_lim or best_max < eps or mu_min > 1e32:
+                    done = it
+                    break
+            launch(_lib.ALQP_IPM_STEP, 0, it)
+        launch(_lib.ALQP_IPM_FINAL)
+        out["iters"] = done
+        return out
+
+    def ipm_backward(self, dims, Cd, F, lams, slacks, g):
+        """DenseQPFunction.backward's KKT solve (qp.py:243-252) -> dx [B,T*n], dlam [B,2*T*nu], dnu [B,T*nx]."""
+        B, T, nx, nu = dims
+        n = nx + nu
+        dt, dev = g.dtype, g.device
+        sfx = _dt(g)
+        d = _lib.AlqpDims(B, T, nx, nu)
+        ws, need = self._ipm_ws(dims, g)
+        dx = torch.empty(B, T * n, dtype=dt, device=dev)
+        dlam = torch.empty(B, 2 * T * nu, dtype=dt, device=dev)
+        dnu = torch.empty(B, T * nx, dtype=dt, device=dev)
+        fn = getattr(self.lib, "alqp_ipm_backward_" + sfx)
+        rc = fn(C.byref(d), _ptr(Cd, "Cd", dt), _ptr(F, "F", dt), B * n, n, B * nx * n, nx * n, _ptr(lams, "lams", dt),
+                _ptr(slacks, "slacks", dt), _ptr(g, "gbar", dt), _ptr(ws, "workspace", dt), need, _ptr(dx, "dx", dt),
+                _ptr(dlam, "dlam", dt), _ptr(dnu, "dnu", dt), None, _stream())
+        _lib.check(rc, "alqp_ipm_backward_" + sfx)
+        return dx, dlam, dnu
+
+
 _default = None
 
 

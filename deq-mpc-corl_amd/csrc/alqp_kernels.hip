@@ -10,6 +10,7 @@
 #include "alqp_team.hpp"
 #include "alqp_quad.hpp"
 #include "mi_alqp.h"
+#include "alqp_dims.hpp"
 
 #ifndef ALQP_PART
 #define ALQP_PART 0
@@ -610,10 +611,7 @@ __global__ __launch_bounds__(64) void k_dual(AuxArgs<real> a) {
 
 // ---- dispatch -------------------------------------------------------------------------
 
-// (nx, nu) instances compiled into the library. Anything else is ALQP_E_UNSUPPORTED:
-// the product path fails loudly rather than falling back to a slow generic route.
-#define ALQP_FOR_EACH_DIMS(X) \
-    X(2, 1) X(4, 1) X(4, 2) X(6, 1) X(6, 2) X(8, 2) X(10, 3) X(12, 4) X(13, 4) X(14, 4)
+// (nx, nu) instances compiled into the library: alqp_dims.hpp (shared with alqp_ipm.hip).
 
 constexpr size_t kMaxLds = 160 * 1024;
 
@@ -1159,7 +1157,7 @@ __global__ void k_exit_test(const double *sumsq, double *ctl, int mode, double t
 #if ALQP_BUILD_MAIN
 extern "C" {
 
-int alqp_abi_version(void) { return 4; }
+int alqp_abi_version(void) { return 5; }
 
 int alqp_dyn_pendulum1l_f32(long K, const void *x, const void *u, double h, const void *h_pt, void *xnext, void *F, void *stream) {
     return alqp::dyn_pendulum1l_impl<float>(K, x, u, h, h_pt, xnext, F, stream);

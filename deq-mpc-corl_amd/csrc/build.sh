@@ -1,6 +1,7 @@
 #!/bin/bash
 # Builds libmi_alqp.so for gfx950 (MI355X). hipcc cross-compiles without a GPU.
-# alqp_kernels.hip is compiled as three objects in parallel (team+ABI, quad fp32, quad fp64).
+# alqp_kernels.hip is compiled as three objects in parallel (team+ABI, quad fp32, quad fp64),
+# alqp_ipm.hip (interior-point path) as a fourth.
 set -euo pipefail
 cd "$(dirname "$0")"
 # -pragma-unroll-threshold: the panel loops of alqp_quad.hpp must be fully unrolled (register
@@ -12,5 +13,7 @@ for part in 1 2 3; do
   hipcc $FLAGS -DALQP_PART=$part -c alqp_kernels.hip -o build/alqp_part$part.o "$@" &
   pids+=($!)
 done
+hipcc $FLAGS -c alqp_ipm.hip -o build/alqp_ipm.o "$@" &
+pids+=($!)
 for p in "${pids[@]}"; do wait "$p"; done
-hipcc --offload-arch=gfx950 -shared -fPIC build/alqp_part1.o build/alqp_part2.o build/alqp_part3.o -o libmi_alqp.so
+hipcc --offload-arch=gfx950 -shared -fPIC build/alqp_part1.o build/alqp_part2.o build/alqp_part3.o build/alqp_ipm.o -o libmi_alqp.so

@@ -255,6 +255,68 @@ int alqp_solve_nonlin_f64(const AlqpDims *dims, const AlqpParams *prm, int dyn_i
                           void *z, void *lam, void *rho, void *phi, void *rnorm2, int *info, unsigned char *status,
                           void *workspace, size_t ws_bytes, void *stream);
 
+/*
+ * ---- Interior-point QP solve (the `--solver_type ip` path) -------------------------------------------
+ * Replaces qp.DenseQPFunction (qpth/qp.py:187-270) = pdipm_b_LU.forward / solve_kkt
+ * (qpth/solvers/pdipm/batch_LU.py:29-244) on the QP that qp_wrapper.MPC.single_qp assembles
+ * (qpth/qp_wrapper.py:295-321, 612-653):
+ *     min 1/2 z'Qz + p'z  s.t.  u_lower <= u_t <= u_upper,  F_t tau_t + f_t = x_{t+1},  x_0 = x0
+ * with DIAGONAL Q (what policies.Tracking_MPC builds). Same regularised KKT system (KKTeps = 1e-7), same
+ * refinement step, same predictor-corrector iteration; no dense matrix is formed (csrc/alqp_ipm.hip).
+ *   Cd, c  diag(C_t) and c_t, element (t, b, k) at t*sC_t + b*sC_b + k      (time-major [T,B,n]: sC_t = B*n, sC_b = n)
+ *   F      [.][nx][n] blocks at t*sF_t + b*sF_b;  f [.][nx] at t*sf_t + b*sf_b
+ *   x0 [B][nx]; u_hi, u_lo [nu]
+ *   zhat [B][T*n]; nus [B][T*nx] (dynamics rows t*nx+i, then the initial-state rows);
+ *   lams, slacks [B][2*T*nu] (upper-bound rows t*nu+j, then lower-bound rows T*nu + t*nu+j)   - the
+ *   reference's orderings (qp_wrapper.py:194-207)
+ *   ry_ext nullable [B][T*nx]: the caller's equality residual at the current iterate (the reference
+ *   evaluates the TRUE dynamics there: dyn_res callback, qp_wrapper.py:306, batch_LU.py:95); NULL: A z - b
+ *   workspace: alqp_ipm_workspace_bytes(); it carries the iterate between launches of one solve.
+ * flags: ALQP_IPM_INIT  initial point (batch_LU.py:44-81)
+ *        ALQP_IPM_LOOP  max_iter x [residuals + best iterate ; predictor-corrector step] in this launch
+ *                       (exit mode "fixed": no batch-global exit rule, best iterate per instance)
+ *        ALQP_IPM_RESID residuals + best-iterate update of iteration iter0 (improved[b], resid[b] = best
+ *                       residual, mu[b] for the reference's batch-global exit rule, :147-151, taken by the host)
+ *        ALQP_IPM_STEP  one predictor-corrector step (:153-197)
+ *        ALQP_IPM_FINAL copy the best iterate to zhat / nus / lams / slacks
+ * info[b]: 0, or block*nx + pivot + 1 of the first non-positive pivot of the Schur complement (sticky).
+ */
+#define ALQP_IPM_INIT  1
+#define ALQP_IPM_RESID 2
+#define ALQP_IPM_STEP  4
+#define ALQP_IPM_LOOP  8
+#define ALQP_IPM_FINAL 16
+
+typedef struct AlqpIpmParams {
+    int flags;       /* ALQP_IPM_* */
+    int max_iter;    /* iterations of an ALQP_IPM_LOOP launch (reference: maxIter = 20, qp.py:203) */
+    int iter0;       /* index of the (first) iteration this launch works on */
+    double kkt_eps;  /* reference: 1e-7 (batch_LU.py:43) */
+} AlqpIpmParams;
+
+size_t alqp_ipm_workspace_bytes(const AlqpDims *dims, int is_f64);
+int alqp_ipm_solve_f32(const AlqpDims *dims, const AlqpIpmParams *prm, const void *Cd, const void *c,
+                       const void *F, const void *f, const void *x0, const void *u_hi, const void *u_lo,
+                       long sC_t, long sC_b, long sF_t, long sF_b, long sf_t, long sf_b, void *workspace,
+                       size_t ws_bytes, const void *ry_ext, void *zhat, void *nus, void *lams, void *slacks,
+                       void *resid, void *mu, int *iter_best, int *improved, int *info, void *stream);
+int alqp_ipm_solve_f64(const AlqpDims *dims, const AlqpIpmParams *prm, const void *Cd, const void *c,
+                       const void *F, const void *f, const void *x0, const void *u_hi, const void *u_lo,
+                       long sC_t, long sC_b, long sF_t, long sF_b, long sf_t, long sf_b, void *workspace,
+                       size_t ws_bytes, const void *ry_ext, void *zhat, void *nus, void *lams, void *slacks,
+                       void *resid, void *mu, int *iter_best, int *improved, int *info, void *stream);
+/*
+ * Backward of the QP layer (DenseQPFunction.backward, qp.py:238-252): one KKT solve, without
+ * regularisation, at the returned lams / slacks: K (dx, ds, dlam, dnu) = -(gbar, 0, 0, 0).
+ * The caller forms the reference's gradient formulas (:254-268) from dx, dlam, dnu.
+ */
+int alqp_ipm_backward_f32(const AlqpDims *dims, const void *Cd, const void *F, long sC_t, long sC_b, long sF_t,
+                          long sF_b, const void *lams, const void *slacks, const void *gbar, void *workspace,
+                          size_t ws_bytes, void *dx, void *dlam, void *dnu, int *info, void *stream);
+int alqp_ipm_backward_f64(const AlqpDims *dims, const void *Cd, const void *F, long sC_t, long sC_b, long sF_t,
+                          long sF_b, const void *lams, const void *slacks, const void *gbar, void *workspace,
+                          size_t ws_bytes, void *dx, void *dlam, void *dnu, int *info, void *stream);
+
 int alqp_abi_version(void);
 
 #ifdef __cplusplus
