@@ -98,7 +98,11 @@ def _replay_ip(name, backend, dev, exit_mode="reference"):
     ex = np.abs(x.detach().cpu().numpy() - g["x"]).max()
     eu = np.abs(u.detach().cpu().numpy() - g["u"]).max()
     assert ex < tol * max(1.0, np.abs(g["x"]).max()) and eu < tol, (ex, eu)
-    assert np.allclose(mpc.last_alpha.cpu().numpy(), g["alpha"][-1])
+    if exit_mode == "reference" or g["qp_iter"] == 1:
+        # (in the SQP fixtures the last line search runs at a converged point, where "did the rollout cost
+        #  strictly decrease" is decided by the last bits of the QP solution: only comparable when the
+        #  interior-point iteration stopped where the reference's did)
+        assert np.allclose(mpc.last_alpha.cpu().numpy(), g["alpha"][-1])
     if with_grad:
         loss = (x * tt(g["bwd_wx"])).sum() + (u * tt(g["bwd_wu"])).sum()
         loss.backward()
