@@ -31,6 +31,10 @@ class AlqpTrace(C.Structure):
                 ("phi_prev", C.c_void_p), ("k", C.c_void_p), ("accept", C.c_void_p)]
 
 
+class AlqpObstacles(C.Structure):
+    _fields_ = [("pos", C.c_void_p), ("radius", C.c_double), ("nobs", C.c_int)]
+
+
 class AlqpIpmParams(C.Structure):
     _fields_ = [("flags", C.c_int), ("max_iter", C.c_int), ("iter0", C.c_int), ("kkt_eps", C.c_double)]
 
@@ -65,6 +69,12 @@ _SIGS = {
                                    C.c_double, _P]),
     "alqp_backward": (C.c_int, [C.POINTER(AlqpDims), _P, _P, _P, _P, _P, _P, _P, _P]),
     "alqp_backward_ws": (C.c_int, [C.POINTER(AlqpDims), _P, C.c_size_t, _P, _P, _P, _P, _P, _P, _P]),
+    "alqp_newton_step_obs": (C.c_int, [C.POINTER(AlqpDims), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P,
+                                       C.c_long, C.c_long, C.POINTER(AlqpObstacles), _P, _P, _P, _P, _P]),
+    "alqp_merit_obs": (C.c_int, [C.POINTER(AlqpDims), C.c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P,
+                                 C.c_long, C.c_long, C.POINTER(AlqpObstacles), _P, _P, _P]),
+    "alqp_dual_update_obs": (C.c_int, [C.POINTER(AlqpDims), _P, _P, _P, _P, _P, C.c_long, C.c_long,
+                                       C.POINTER(AlqpObstacles), _P, _P, C.c_double, _P]),
     "alqp_ipm_solve": (C.c_int, [C.POINTER(AlqpDims), C.POINTER(AlqpIpmParams), _P, _P, _P, _P, _P, _P, _P,
                                  C.c_long, C.c_long, C.c_long, C.c_long, C.c_long, C.c_long, _P, C.c_size_t, _P,
                                  _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),

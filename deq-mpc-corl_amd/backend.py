@@ -215,30 +215,47 @@ class HipBackend:
                                      int(mode), float(tol), _stream())
         _lib.check(rc, "alqp_exit_test")
 
+    @staticmethod
+    def _obs_struct(obs, dims, dt):
+        """obs = (pos [B,T,nobs,3] tensor, radius float) -> AlqpObstacles (Obstacle_MPC rows)."""
+        pos, radius = obs
+        B, T = dims[0], dims[1]
+        if pos.dim() != 4 or pos.shape[0] != B or pos.shape[1] != T or pos.shape[3] != 3:
+            raise ValueError(f"mi_alqp: obstacle centres must be [B,T,nobs,3], got {tuple(pos.shape)}")
+        return _lib.AlqpObstacles(_ptr(pos, "obstacle centres", dt).value, float(radius), int(pos.shape[2]))
+
     def newton_step(self, dims, z, xnext, F, x0, lam, rho, Qd, q, ulo, uhi, sb_u, st_u, d_out,
-                    g_out=None, factor=None, info=None):
+                    g_out=None, factor=None, info=None, obs=None):
         B, T, nx, nu = dims
         dt = z.dtype
         sfx = _dt(z)
         d = _lib.AlqpDims(B, T, nx, nu)
-        fn = getattr(self.lib, "alqp_newton_step_" + sfx)
-        rc = fn(C.byref(d), _ptr(z, "z", dt), _ptr(xnext, "xnext", dt), _ptr(F, "F", dt),
+        head = (C.byref(d), _ptr(z, "z", dt), _ptr(xnext, "xnext", dt), _ptr(F, "F", dt),
                 _ptr(x0, "x0", dt), _ptr(lam, "lam", dt), _ptr(rho, "rho", dt), _ptr(Qd, "Qd", dt),
-                _ptr(q, "q", dt), _ptr(ulo, "u_lower", dt), _ptr(uhi, "u_upper", dt), sb_u, st_u,
-                _ptr(d_out, "d_out", dt), _ptr(g_out, "g_out", dt, True),
+                _ptr(q, "q", dt), _ptr(ulo, "u_lower", dt), _ptr(uhi, "u_upper", dt), sb_u, st_u)
+        tail = (_ptr(d_out, "d_out", dt), _ptr(g_out, "g_out", dt, True),
                 _ptr(factor, "factor", dt, True), _ptr(info, "info", torch.int32, True), _stream())
+        if obs is None:
+            rc = getattr(self.lib, "alqp_newton_step_" + sfx)(*head, *tail)
+        else:
+            o = self._obs_struct(obs, dims, dt)
+            rc = getattr(self.lib, "alqp_newton_step_obs_" + sfx)(*head, C.byref(o), *tail)
         _lib.check(rc, "alqp_newton_step_" + sfx)
 
-    def merit(self, dims, K, zc, xnext, x0, lam, rho, Qd, q, ulo, uhi, sb_u, st_u, phi, rnorm2=None):
+    def merit(self, dims, K, zc, xnext, x0, lam, rho, Qd, q, ulo, uhi, sb_u, st_u, phi, rnorm2=None, obs=None):
         B, T, nx, nu = dims
         dt = zc.dtype
         sfx = _dt(zc)
         d = _lib.AlqpDims(B, T, nx, nu)
-        fn = getattr(self.lib, "alqp_merit_" + sfx)
-        rc = fn(C.byref(d), K, _ptr(zc, "zc", dt), _ptr(xnext, "xnext", dt), _ptr(x0, "x0", dt),
+        head = (C.byref(d), K, _ptr(zc, "zc", dt), _ptr(xnext, "xnext", dt), _ptr(x0, "x0", dt),
                 _ptr(lam, "lam", dt), _ptr(rho, "rho", dt), _ptr(Qd, "Qd", dt), _ptr(q, "q", dt),
-                _ptr(ulo, "u_lower", dt), _ptr(uhi, "u_upper", dt), sb_u, st_u,
-                _ptr(phi, "phi", dt), _ptr(rnorm2, "rnorm2", dt, True), _stream())
+                _ptr(ulo, "u_lower", dt), _ptr(uhi, "u_upper", dt), sb_u, st_u)
+        tail = (_ptr(phi, "phi", dt), _ptr(rnorm2, "rnorm2", dt, True), _stream())
+        if obs is None:
+            rc = getattr(self.lib, "alqp_merit_" + sfx)(*head, *tail)
+        else:
+            o = self._obs_struct(obs, dims, dt)
+            rc = getattr(self.lib, "alqp_merit_obs_" + sfx)(*head, C.byref(o), *tail)
         _lib.check(rc, "alqp_merit_" + sfx)
 
     def linesearch_pick(self, dims, n_ls, phi, phi_prev, d, z, k_out=None, accept_out=None):
@@ -252,15 +269,19 @@ class HipBackend:
                 _ptr(accept_out, "accept_out", torch.int32, True), _stream())
         _lib.check(rc, "alqp_linesearch_pick_" + sfx)
 
-    def dual_update(self, dims, z, xnext, x0, ulo, uhi, sb_u, st_u, lam, rho, rho_scale=10.0):
+    def dual_update(self, dims, z, xnext, x0, ulo, uhi, sb_u, st_u, lam, rho, rho_scale=10.0, obs=None):
         B, T, nx, nu = dims
         dt = z.dtype
         sfx = _dt(z)
         d = _lib.AlqpDims(B, T, nx, nu)
-        fn = getattr(self.lib, "alqp_dual_update_" + sfx)
-        rc = fn(C.byref(d), _ptr(z, "z", dt), _ptr(xnext, "xnext", dt), _ptr(x0, "x0", dt),
-                _ptr(ulo, "u_lower", dt), _ptr(uhi, "u_upper", dt), sb_u, st_u,
-                _ptr(lam, "lam", dt), _ptr(rho, "rho", dt), rho_scale, _stream())
+        head = (C.byref(d), _ptr(z, "z", dt), _ptr(xnext, "xnext", dt), _ptr(x0, "x0", dt),
+                _ptr(ulo, "u_lower", dt), _ptr(uhi, "u_upper", dt), sb_u, st_u)
+        tail = (_ptr(lam, "lam", dt), _ptr(rho, "rho", dt), rho_scale, _stream())
+        if obs is None:
+            rc = getattr(self.lib, "alqp_dual_update_" + sfx)(*head, *tail)
+        else:
+            o = self._obs_struct(obs, dims, dt)
+            rc = getattr(self.lib, "alqp_dual_update_obs_" + sfx)(*head, C.byref(o), *tail)
         _lib.check(rc, "alqp_dual_update_" + sfx)
 
     def backward(self, dims, factor, F, rho, z_final, gbar, q_grad, Qd_grad):

@@ -52,6 +52,9 @@ struct StepArgs {
     long sb_u, st_u;
     real *d_out, *g_out, *factor;
     int *info;
+    const real *obs;   // nullable [B][T][nobs][3]: obstacle centres (Obstacle_MPC)
+    int nobs;
+    real obs_r2;
 };
 
 template <typename real>
@@ -423,10 +426,11 @@ __global__ __launch_bounds__(64) void k_newton_step(StepArgs<real> a) {
     const int b_raw = blockIdx.x * C::QPW + team;
     const bool active = b_raw < a.B;
     const int b = active ? b_raw : a.B - 1;
-    const int T = a.T, M = C::M(T);
+    const int T = a.T, M = C::M(T) + T * a.nobs;
 
     Team<real, NX, NU> tm;
     tm.init(smem + (size_t)team * C::team_words(T) + opaque_zero(), li, team * G, T, b);
+    if (a.nobs > 0) { tm.gobs = a.obs + (size_t)b * T * a.nobs * 3; tm.nobs = a.nobs; tm.obs_r2 = a.obs_r2; }
     tm.gQd = a.Qd + (size_t)b * T * N;
     tm.gq = a.q + (size_t)b * T * N;
     tm.gF = a.F + (size_t)b * (T - 1) * NX * N;
@@ -511,7 +515,20 @@ struct AuxArgs {
     // dual
     real *lam_io, *rho_io;
     real rho_scale;
+    // obstacle rows (nullable): centres [B][T][nobs][3], radius^2
+    const real *obs;
+    int nobs;
+    real obs_r2;
 };
+
+// c_k = r^2 - |x_t[0:3] - o_k|^2 for obstacle row e = t*nobs + k of instance b (al_utils.py:313-323)
+template <typename real>
+__device__ inline real obs_row(const AuxArgs<real> &a, const real *z, int b, int e) {
+    const int t = e / a.nobs, n = a.nx + a.nu;
+    const real *o = a.obs + ((size_t)b * a.T * a.nobs + e) * 3;
+    const real d0 = z[t * n] - o[0], d1 = z[t * n + 1] - o[1], d2 = z[t * n + 2] - o[2];
+    return a.obs_r2 - (d0 * d0 + d1 * d1 + d2 * d2);
+}
 
 // merit of candidate kk for instance b (al_utils.py:73-77), block = (kk, b)
 template <typename real>
@@ -521,7 +538,8 @@ __global__ __launch_bounds__(64) void k_merit(AuxArgs<real> a) {
     const int T = a.T, nx = a.nx, nu = a.nu, n = nx + nu, neq = T * nx;
     const real *z = a.zc + ((size_t)kk * a.B + b) * T * n;
     const real *xn = a.xnext + ((size_t)kk * a.B + b) * (T - 1) * nx;
-    const real *lam = a.lam + (size_t)b * (neq + 2 * T * nu);
+    const int nit = 2 * nu + a.nobs;   // inequality rows per stage
+    const real *lam = a.lam + (size_t)b * (neq + T * nit);
     const real *Qd = a.Qd + (size_t)b * T * n, *q = a.q + (size_t)b * T * n;
     const real *ulo = a.ulo + (size_t)b * a.sb_u, *uhi = a.uhi + (size_t)b * a.sb_u;
     const real rho = a.rho[b];
@@ -534,10 +552,15 @@ __global__ __launch_bounds__(64) void k_merit(AuxArgs<real> a) {
             int ju = j - nx;
             real vu = v - uhi[t * a.st_u + ju], vl = -v + ulo[t * a.st_u + ju];
             real cu = vu > 0 ? vu : real(0), cl = vl > 0 ? vl : real(0);
-            int ru = neq + t * 2 * nu + ju;
+            int ru = neq + t * nit + ju;
             acc += lam[ru] * vu + lam[ru + nu] * vl;
             sq += cu * cu + cl * cl;
         }
+    }
+    for (int e = lane; e < T * a.nobs; e += 64) {
+        const real ck = obs_row(a, z, b, e), cp = ck > 0 ? ck : real(0);
+        acc += lam[neq + (e / a.nobs) * nit + 2 * nu + e % a.nobs] * ck;
+        sq += cp * cp;
     }
     for (int e = lane; e < neq; e += 64) {
         int t = e / nx, i = e - t * nx;
@@ -586,7 +609,8 @@ __global__ __launch_bounds__(64) void k_dual(AuxArgs<real> a) {
     const int T = a.T, nx = a.nx, nu = a.nu, n = nx + nu, neq = T * nx;
     const real *z = a.zc + (size_t)b * T * n;
     const real *xn = a.xnext + (size_t)b * (T - 1) * nx;
-    real *lam = a.lam_io + (size_t)b * (neq + 2 * T * nu);
+    const int nit = 2 * nu + a.nobs;
+    real *lam = a.lam_io + (size_t)b * (neq + T * nit);
     const real *ulo = a.ulo + (size_t)b * a.sb_u, *uhi = a.uhi + (size_t)b * a.sb_u;
     const real rho = a.rho_io[b];
     for (int e = lane; e < neq; e += 64) {
@@ -597,11 +621,16 @@ __global__ __launch_bounds__(64) void k_dual(AuxArgs<real> a) {
     for (int e = lane; e < T * nu; e += 64) {
         int t = e / nu, j = e - t * nu;
         real u = z[t * n + nx + j];
-        int ru = neq + t * 2 * nu + j, rl = ru + nu;
+        int ru = neq + t * nit + j, rl = ru + nu;
         real v1 = lam[ru] + rho * (u - uhi[t * a.st_u + j]);
         real v2 = lam[rl] + rho * (-u + ulo[t * a.st_u + j]);
         lam[ru] = v1 < 0 ? real(0) : v1;
         lam[rl] = v2 < 0 ? real(0) : v2;
+    }
+    for (int e = lane; e < T * a.nobs; e += 64) {
+        const int r = neq + (e / a.nobs) * nit + 2 * nu + e % a.nobs;
+        const real v = lam[r] + rho * obs_row(a, z, b, e);
+        lam[r] = v < 0 ? real(0) : v;
     }
     __syncthreads();
     if (lane == 0) a.rho_io[b] = rho * a.rho_scale;
@@ -846,10 +875,12 @@ template <typename real>
 int newton_step_impl(const AlqpDims *dims, const void *z, const void *xnext, const void *F,
                      const void *x0, const void *lam, const void *rho, const void *Qd, const void *q,
                      const void *u_lo, const void *u_hi, long sb_u, long st_u, void *d_out,
-                     void *g_out, void *factor_out, int *info, void *stream) {
+                     void *g_out, void *factor_out, int *info, void *stream, const AlqpObstacles *obs = nullptr) {
     if (!dims_ok(dims) || !z || !xnext || !F || !x0 || !lam || !rho || !Qd || !q || !u_lo || !u_hi || !d_out)
         return ALQP_E_BADARG;
+    if (obs && (obs->nobs < 0 || (obs->nobs > 0 && (!obs->pos || dims->nx < 3)))) return ALQP_E_BADARG;
     StepArgs<real> a = {};
+    if (obs && obs->nobs > 0) { a.obs = (const real *)obs->pos; a.nobs = obs->nobs; a.obs_r2 = (real)(obs->radius * obs->radius); }
     a.B = dims->B; a.T = dims->T;
     a.z = (const real *)z; a.xnext = (const real *)xnext; a.F = (const real *)F; a.x0 = (const real *)x0;
     a.lam = (const real *)lam; a.rho = (const real *)rho; a.Qd = (const real *)Qd; a.q = (const real *)q;
@@ -890,10 +921,13 @@ int backward_ws_impl(const AlqpDims *dims, void *workspace, size_t ws_bytes, con
 template <typename real>
 int merit_impl(const AlqpDims *dims, int K, const void *zc, const void *xnext, const void *x0,
                const void *lam, const void *rho, const void *Qd, const void *q, const void *u_lo,
-               const void *u_hi, long sb_u, long st_u, void *phi, void *rnorm2, void *stream) {
+               const void *u_hi, long sb_u, long st_u, void *phi, void *rnorm2, void *stream,
+               const AlqpObstacles *obs = nullptr) {
     if (!dims_ok(dims) || K < 1 || !zc || !xnext || !x0 || !lam || !rho || !Qd || !q || !u_lo || !u_hi || !phi)
         return ALQP_E_BADARG;
+    if (obs && (obs->nobs < 0 || (obs->nobs > 0 && (!obs->pos || dims->nx < 3)))) return ALQP_E_BADARG;
     AuxArgs<real> a = {};
+    if (obs && obs->nobs > 0) { a.obs = (const real *)obs->pos; a.nobs = obs->nobs; a.obs_r2 = (real)(obs->radius * obs->radius); }
     a.B = dims->B; a.T = dims->T; a.nx = dims->nx; a.nu = dims->nu; a.K = K;
     a.zc = (const real *)zc; a.xnext = (const real *)xnext; a.x0 = (const real *)x0;
     a.lam = (const real *)lam; a.rho = (const real *)rho; a.Qd = (const real *)Qd; a.q = (const real *)q;
@@ -919,9 +953,11 @@ int pick_impl(const AlqpDims *dims, int n_ls, const void *phi, void *phi_prev, c
 template <typename real>
 int dual_impl(const AlqpDims *dims, const void *z, const void *xnext, const void *x0, const void *u_lo,
               const void *u_hi, long sb_u, long st_u, void *lam, void *rho, double rho_scale,
-              void *stream) {
+              void *stream, const AlqpObstacles *obs = nullptr) {
     if (!dims_ok(dims) || !z || !xnext || !x0 || !u_lo || !u_hi || !lam || !rho) return ALQP_E_BADARG;
+    if (obs && (obs->nobs < 0 || (obs->nobs > 0 && (!obs->pos || dims->nx < 3)))) return ALQP_E_BADARG;
     AuxArgs<real> a = {};
+    if (obs && obs->nobs > 0) { a.obs = (const real *)obs->pos; a.nobs = obs->nobs; a.obs_r2 = (real)(obs->radius * obs->radius); }
     a.B = dims->B; a.T = dims->T; a.nx = dims->nx; a.nu = dims->nu;
     a.zc = (const real *)z; a.xnext = (const real *)xnext; a.x0 = (const real *)x0;
     a.ulo = (const real *)u_lo; a.uhi = (const real *)u_hi; a.sb_u = sb_u; a.st_u = st_u;
@@ -1276,6 +1312,33 @@ int alqp_qps_per_wave(const AlqpDims *dims, int is_f64) {
 
 ALQP_DEFINE(f32, float)
 ALQP_DEFINE(f64, double)
+
+#define ALQP_DEFINE_OBS(SFX, REAL)                                                                    \
+    int alqp_newton_step_obs_##SFX(const AlqpDims *dims, const void *z, const void *xnext, const void *F, \
+                                   const void *x0, const void *lam, const void *rho, const void *Qd,  \
+                                   const void *q, const void *u_lo, const void *u_hi, long sb_u,      \
+                                   long st_u, const AlqpObstacles *obs, void *d_out, void *g_out,     \
+                                   void *factor_out, int *info, void *stream) {                       \
+        return alqp::newton_step_impl<REAL>(dims, z, xnext, F, x0, lam, rho, Qd, q, u_lo, u_hi, sb_u, \
+                                            st_u, d_out, g_out, factor_out, info, stream, obs);       \
+    }                                                                                                 \
+    int alqp_merit_obs_##SFX(const AlqpDims *dims, int K, const void *zc, const void *xnext,          \
+                             const void *x0, const void *lam, const void *rho, const void *Qd,        \
+                             const void *q, const void *u_lo, const void *u_hi, long sb_u, long st_u, \
+                             const AlqpObstacles *obs, void *phi, void *rnorm2, void *stream) {       \
+        return alqp::merit_impl<REAL>(dims, K, zc, xnext, x0, lam, rho, Qd, q, u_lo, u_hi, sb_u,      \
+                                      st_u, phi, rnorm2, stream, obs);                                \
+    }                                                                                                 \
+    int alqp_dual_update_obs_##SFX(const AlqpDims *dims, const void *z, const void *xnext,            \
+                                   const void *x0, const void *u_lo, const void *u_hi, long sb_u,     \
+                                   long st_u, const AlqpObstacles *obs, void *lam, void *rho,         \
+                                   double rho_scale, void *stream) {                                  \
+        return alqp::dual_impl<REAL>(dims, z, xnext, x0, u_lo, u_hi, sb_u, st_u, lam, rho, rho_scale, \
+                                     stream, obs);                                                    \
+    }
+
+ALQP_DEFINE_OBS(f32, float)
+ALQP_DEFINE_OBS(f64, double)
 
 int alqp_backward_ws_f32(const AlqpDims *dims, void *workspace, size_t ws_bytes, const void *F,
                          const void *rho, const void *z_final, const void *gbar, void *q_grad,

@@ -170,6 +170,11 @@ struct Team {
     long st_u;
     real rho;
     int info;
+    // obstacle rows (Obstacle_MPC, qpth/AL_mpc_custom.py; al_utils.py:313-323, 351-388): nobs spheres per
+    // stage, c_k = r^2 - |x_t[0:3] - o_k|^2 <= 0, behind the stage's 2 NU bound rows. 0 = plain problem.
+    const real *gobs;   // this instance's centres [T][nobs][3] (global memory)
+    int nobs;
+    real obs_r2;
 
     // `lds_team` must not be provably wave-uniform (see the kernels): uniform LDS reads
     // get scalarised by the compiler into ds_read + v_readfirstlane + SGPR-spill chains.
@@ -199,6 +204,7 @@ struct Team {
         }
         info = 0;
         gxnext = nullptr;
+        gobs = nullptr; nobs = 0; obs_r2 = 0;
         // constant zero rows / pads of the SYRK operands
         for (int e = li; e < RB * NXP; e += G) Ft[e] = 0;
         for (int e = li; e < RB * NP; e += G) Sb[e] = 0;
@@ -308,8 +314,8 @@ struct Team {
             if (t + 1 < T) {
                 if (isHx) lan = lams[t * NX + hi];
                 if (isHu) {
-                    lan = lams[T * NX + (t + 1) * 2 * NU + (hi - NX)];
-                    lbn = lams[T * NX + (t + 1) * 2 * NU + NU + (hi - NX)];
+                    lan = lams[T * NX + (t + 1) * (2 * NU + nobs) + (hi - NX)];
+                    lbn = lams[T * NX + (t + 1) * (2 * NU + nobs) + NU + (hi - NX)];
                 }
             }
             // ---- dynamics residual r_t and multiplier estimate v = lam + rho r (W lanes)
@@ -326,6 +332,7 @@ struct Team {
             wave_sync();
             // ---- gradient entry and diagonal of H_tt (H lanes), al_utils.py:113-120
             real D = 0;
+            real hob[3] = {0, 0, 0};   // obstacle rows: rho J_k'J_k entries (hi, 0..2) of the active rows
             if (isH) {
                 real zv = zs[t * N + hi];
                 real g = fma_(Qv, zv, qv);
@@ -352,6 +359,24 @@ struct Team {
                             if (r4 + i < NX) s = fma_(fa[r4 + i], v4[i], s);
                     }
                     g -= s;
+                }
+                if constexpr (NX >= 3) {
+                    if (nobs > 0 && hi < 3) {
+                        // J_k = -2 (p - o_k)' on x_t[0:3]: g += (lam_k + rho max(c_k, 0)) J_k', and for the
+                        // rows with c_k >= 0 the Gauss-Newton term rho J_k'J_k (al_utils.py:373-386, 113-120)
+                        const real *lk = lams + T * NX + t * (2 * NU + nobs) + 2 * NU;
+                        for (int k = 0; k < nobs; ++k) {
+                            const real *o = gobs + (size_t)(t * nobs + k) * 3;
+                            const real d0 = zs[t * N] - o[0], d1 = zs[t * N + 1] - o[1], d2 = zs[t * N + 2] - o[2];
+                            const real ck = obs_r2 - fma_(d0, d0, fma_(d1, d1, d2 * d2));
+                            const real dh = hi == 0 ? d0 : (hi == 1 ? d1 : d2);
+                            g = fma_(fma_(rho, ck > 0 ? ck : real(0), lk[k]), real(-2) * dh, g);
+                            if (ck >= 0) {
+                                const real w4 = real(4) * rho * dh;
+                                hob[0] = fma_(w4, d0, hob[0]); hob[1] = fma_(w4, d1, hob[1]); hob[2] = fma_(w4, d2, hob[2]);
+                            }
+                        }
+                    }
                 }
                 gs[hi] = g;
                 if (g_out) g_out[t * N + hi] = g;
@@ -393,6 +418,11 @@ struct Team {
             wave_sync();
             // ---- diagonal of H_tt on top of the SYRK result (same lane order: in-order LDS)
             if (isH) Hs[hi * HP + hi] += D;
+            if constexpr (NX >= 3) {
+                if (nobs > 0 && isH && hi < 3) {
+                    Hs[hi * HP + 0] += hob[0]; Hs[hi * HP + 1] += hob[1]; Hs[hi * HP + 2] += hob[2];
+                }
+            }
             wave_sync();
             // ---- initial row values of the panel: H rows / rhs row from LDS, W rows (-rho F_t)
             //      from registers, identity rows start at 0 and get their 1 at column ui

@@ -267,8 +267,14 @@ class MPC(Module):
         return self._al_solve(x, u, dx, dx_jac, x0, cost.C, cost.c, True)
 
     # -- internals -------------------------------------------------------------------
+    def _obs_kwargs(self, dtype, device):
+        """Extra backend arguments of the obstacle rows; the plain MPC has none."""
+        return {}
+
     def _as_lindx(self, dx, B):
         """(F[B,T-1,nx,n], c[B,T-1,nx]) if `dx` carries affine data, else None."""
+        if self._obs_kwargs(self.dtype, "cpu"):
+            return None   # obstacle rows exist only in the nonlinear-caller building blocks
         F = getattr(dx, "F", None)
         c = getattr(dx, "f", None)
         if F is None or c is None or not torch.is_tensor(F):
@@ -454,8 +460,9 @@ class MPC(Module):
             xn = st.dx(zz[..., :-1, :nx].reshape(-1, nx), zz[..., :-1, nx:].reshape(-1, nu))
             return xn.reshape(*lead, T - 1, nx).to(dt).contiguous()
 
+        okw = self._obs_kwargs(dt, z.device)   # {} or {"obs": (centres, radius)} (Obstacle_MPC)
         xn = dyn(z)
-        be.merit(dims, 1, z, xn, st.x0, st.lam, st.rho, Qd, q, lo, hi, sb, stt, ws["phi"], ws["rn2"])
+        be.merit(dims, 1, z, xn, st.x0, st.lam, st.rho, Qd, q, lo, hi, sb, stt, ws["phi"], ws["rn2"], **okw)
         old = self._global_norm(ws["rn2"]) if self.exit_mode == "reference" else None
         alphas = (2.0 ** -torch.arange(N_LS, device=z.device, dtype=dt)).view(N_LS, 1, 1, 1)
         steps = 0
@@ -463,13 +470,13 @@ class MPC(Module):
             steps += 1
             xn, F = self._linearize(st, z)
             be.newton_step(dims, z, xn, F, st.x0, st.lam, st.rho, Qd, q, lo, hi, sb, stt, ws["d"],
-                           factor=ws.get("factor") if need_factor else None, info=ws["info"])
+                           factor=ws.get("factor") if need_factor else None, info=ws["info"], **okw)
             if need_factor:
                 ws["F_last"] = F
             zc = (z.unsqueeze(0) + alphas * ws["d"].unsqueeze(0)).contiguous()
             xnc = dyn(zc)
             be.merit(dims, N_LS, zc, xnc, st.x0, st.lam, st.rho, Qd, q, lo, hi, sb, stt,
-                     ws["phis"], ws["rn2s"])
+                     ws["phis"], ws["rn2s"], **okw)
             be.linesearch_pick(dims, N_LS, ws["phis"], ws["phi"], ws["d"], z, ws["k"], ws["acc"])
             if self.exit_mode == "reference":
                 rn2 = torch.where(ws["acc"].bool(), ws["rn2s"].gather(0, ws["k"].long().unsqueeze(0)).squeeze(0),
@@ -517,6 +524,10 @@ class MPC(Module):
             raise TypeError("MPC: linearize_once is only defined for the streaming route (after "
                             "warm_start_initialize); the reference's al_solve raises TypeError on it as well")
         linearize_once = bool(self.linearize_once) and stream
+        has_obs = bool(self._obs_kwargs(dt, dev))
+        if has_obs and linearize_once:
+            raise NotImplementedError("Obstacle_MPC with linearize_once: the reference's frozen-linearisation "
+                                      "module knows no obstacle rows (AL_mpc_custom.py:68, 75, 83)")
         npa = []
         rho_last = None
         F_last = None
@@ -555,7 +566,7 @@ class MPC(Module):
             npa = [MAX_NEWTON] * self.al_iter
             rho_last = st.rho / RHO_SCALE
             F_last = F
-        elif (F is None and not stream and self.exit_mode == "fixed"
+        elif (F is None and not stream and self.exit_mode == "fixed" and not has_obs
               and getattr(st.dx, "fused_id", None) is not None and hasattr(be, "solve_nonlin")
               and (getattr(st.dx, "fused_default", True) or self.prefer_fused)
               and (getattr(st.dx, "nx", None), getattr(st.dx, "nu", None)) == (nx, nu)):
@@ -580,7 +591,7 @@ class MPC(Module):
                 be.merit(dims, 1, st.z, xn, st.x0, st.lam, st.rho, Qd, q, lo, hi, sb, stt,
                          ws["phi"], ws["rn2"])
                 prev_mean = self._global_mean(ws["rn2"].sqrt())
-            fused_nl = (F is None and not stream and self.exit_mode == "reference"
+            fused_nl = (F is None and not stream and self.exit_mode == "reference" and not has_obs
                         and getattr(st.dx, "fused_id", None) is not None and hasattr(be, "solve_nonlin")
                         and (getattr(st.dx, "fused_default", True) or self.prefer_fused)
                         and (getattr(st.dx, "nx", None), getattr(st.dx, "nu", None)) == (nx, nu))
@@ -618,9 +629,10 @@ class MPC(Module):
                     ws["primed"] = wsc if getattr(be, "last_variant", None) == "quad" else None
                 else:
                     xn = true_next(st.z)
+                    okw = self._obs_kwargs(dt, dev)
                     be.merit(dims, 1, st.z, xn, st.x0, st.lam, st.rho, Qd, q, lo, hi, sb, stt,
-                             ws["phi"], ws["rn2"])
-                    be.dual_update(dims, st.z, xn, st.x0, lo, hi, sb, stt, st.lam, st.rho, RHO_SCALE)
+                             ws["phi"], ws["rn2"], **okw)
+                    be.dual_update(dims, st.z, xn, st.x0, lo, hi, sb, stt, st.lam, st.rho, RHO_SCALE, **okw)
                     ws["primed"] = None   # lam/rho changed behind the workspace records' back
                 if stream:
                     if linearize_once:

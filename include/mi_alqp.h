@@ -256,6 +256,45 @@ int alqp_solve_nonlin_f64(const AlqpDims *dims, const AlqpParams *prm, int dyn_i
                           void *workspace, size_t ws_bytes, void *stream);
 
 /*
+ * ---- Obstacle inequalities (Obstacle_MPC, qpth/AL_mpc_custom.py:22-135; al_utils.py:313-323, 351-388) ----
+ * `nobs` spheres per stage add the rows  c_k = radius^2 - |x_t[0:3] - pos_k|^2 <= 0  behind the stage's
+ * 2 nu bound rows: lam [B][M], M = T*nx + T*(2*nu + nobs), inequality row T*nx + t*(2*nu + nobs) + j with
+ * j < nu upper, j < 2 nu lower, then obstacle j - 2 nu (the reference's stage-major order, al_utils.py:376).
+ * The Newton step gets the rank-<=nobs Gauss-Newton update 4 rho (p - o_k)(p - o_k)' of the position corner
+ * of H_tt for the rows with c_k >= 0 and the gradient term (lam_k + rho max(c_k, 0)) (-2)(p - o_k).
+ * These are the nonlinear-caller building blocks with obstacles (the reference only reaches Obstacle_MPC
+ * with PyTorch-coded dynamics); arguments as their plain twins. nx >= 3 required.
+ */
+typedef struct AlqpObstacles {
+    const void *pos;   /* DEVICE [B][T][nobs][3], the real type of the call */
+    double radius;
+    int nobs;          /* reference: 4 nearest of 40 (AL_mpc_custom.py:52-54, 112-115) */
+} AlqpObstacles;
+
+int alqp_newton_step_obs_f32(const AlqpDims *dims, const void *z, const void *xnext, const void *F,
+                             const void *x0, const void *lam, const void *rho, const void *Qd, const void *q,
+                             const void *u_lo, const void *u_hi, long sb_u, long st_u, const AlqpObstacles *obs,
+                             void *d_out, void *g_out, void *factor_out, int *info, void *stream);
+int alqp_newton_step_obs_f64(const AlqpDims *dims, const void *z, const void *xnext, const void *F,
+                             const void *x0, const void *lam, const void *rho, const void *Qd, const void *q,
+                             const void *u_lo, const void *u_hi, long sb_u, long st_u, const AlqpObstacles *obs,
+                             void *d_out, void *g_out, void *factor_out, int *info, void *stream);
+int alqp_merit_obs_f32(const AlqpDims *dims, int K, const void *zc, const void *xnext, const void *x0,
+                       const void *lam, const void *rho, const void *Qd, const void *q, const void *u_lo,
+                       const void *u_hi, long sb_u, long st_u, const AlqpObstacles *obs, void *phi, void *rnorm2,
+                       void *stream);
+int alqp_merit_obs_f64(const AlqpDims *dims, int K, const void *zc, const void *xnext, const void *x0,
+                       const void *lam, const void *rho, const void *Qd, const void *q, const void *u_lo,
+                       const void *u_hi, long sb_u, long st_u, const AlqpObstacles *obs, void *phi, void *rnorm2,
+                       void *stream);
+int alqp_dual_update_obs_f32(const AlqpDims *dims, const void *z, const void *xnext, const void *x0,
+                             const void *u_lo, const void *u_hi, long sb_u, long st_u, const AlqpObstacles *obs,
+                             void *lam, void *rho, double rho_scale, void *stream);
+int alqp_dual_update_obs_f64(const AlqpDims *dims, const void *z, const void *xnext, const void *x0,
+                             const void *u_lo, const void *u_hi, long sb_u, long st_u, const AlqpObstacles *obs,
+                             void *lam, void *rho, double rho_scale, void *stream);
+
+/*
  * ---- Interior-point QP solve (the `--solver_type ip` path) -------------------------------------------
  * Replaces qp.DenseQPFunction (qpth/qp.py:187-270) = pdipm_b_LU.forward / solve_kkt
  * (qpth/solvers/pdipm/batch_LU.py:29-244) on the QP that qp_wrapper.MPC.single_qp assembles

@@ -23,13 +23,29 @@
 #define CAT(a, b) CAT_(a, b)
 #define FN(name) CAT(name, SFX)
 
+/* ---- obstacle rows (Obstacle_MPC, qpth/AL_mpc_custom.py:22-135; al_utils.py:313-323, 351-388) ------
+ * Optional: after orc_set_obstacles(pos[B][T][nobs][3], nobs, radius) every stage carries `nobs` more
+ * inequality rows  c_k = radius^2 - |x_t[0:3] - pos_k|^2 <= 0  behind its 2 nu bound rows (stage-major
+ * row order: upper, lower, obstacles - al_utils.py:376), with Jacobian -2 (x_t[0:3] - pos_k)' on the
+ * first three states. nobs = 0 (default) is the plain problem. Test infrastructure: process-global. */
+static const REAL *FN(g_obs) = 0;
+static int FN(g_nobs) = 0;
+static REAL FN(g_obs_r2) = 0;
+void FN(orc_set_obstacles)(const REAL *pos, int nobs, double radius)
+{
+    FN(g_obs) = pos; FN(g_nobs) = pos ? nobs : 0; FN(g_obs_r2) = (REAL)(radius * radius);
+}
+#define NOBS (FN(g_nobs))
+#define NINEQ_T (2 * nu + NOBS)                      /* inequality rows per stage */
+#define OBS_OF(b) (FN(g_obs) ? FN(g_obs) + (long)(b) * T * NOBS * 3 : (const REAL *)0)
+
 /* ---- residuals ------------------------------------------------------------ */
 
 /* Equality + inequality residuals of one instance, given x_next = f(x_t,u_t).
  * qpth/al_utils.py:209-226 (dyn_res_eq), :288-326 (dyn_res_ineq). */
 static void FN(residual_one)(int T, int nx, int nu, const REAL *z, const REAL *xnext,
                              const REAL *x0, const REAL *ulo, const REAL *uhi, long st_u,
-                             REAL *res /*[M]*/)
+                             REAL *res /*[M]*/, const REAL *obs /*[T][nobs][3] or NULL*/)
 {
     int n = nx + nu, neq = T * nx;
     for (int t = 0; t < T - 1; ++t)
@@ -40,9 +56,19 @@ static void FN(residual_one)(int T, int nx, int nu, const REAL *z, const REAL *x
     for (int t = 0; t < T; ++t)
         for (int j = 0; j < nu; ++j) {
             REAL u = z[t * n + nx + j];
-            res[neq + t * 2 * nu + j] = u - uhi[t * st_u + j];
-            res[neq + t * 2 * nu + nu + j] = -u + ulo[t * st_u + j];
+            res[neq + t * NINEQ_T + j] = u - uhi[t * st_u + j];
+            res[neq + t * NINEQ_T + nu + j] = -u + ulo[t * st_u + j];
         }
+    if (obs)
+        for (int t = 0; t < T; ++t)
+            for (int k = 0; k < NOBS; ++k) {
+                REAL d2 = 0;
+                for (int a = 0; a < 3; ++a) {
+                    REAL dv = z[t * n + a] - obs[(t * NOBS + k) * 3 + a];
+                    d2 += dv * dv;
+                }
+                res[neq + t * NINEQ_T + 2 * nu + k] = FN(g_obs_r2) - d2;
+            }
 }
 
 /* x_next for affine dynamics: F_t [x_t;u_t] + c_t  (the synthetic `dx`). */
@@ -64,7 +90,7 @@ static void FN(affine_next_one)(int T, int nx, int nu, const REAL *z, const REAL
 static REAL FN(merit_one)(int T, int nx, int nu, const REAL *z, const REAL *res,
                           const REAL *lam, REAL rho, const REAL *Qd, const REAL *q, REAL *rp2)
 {
-    int n = nx + nu, neq = T * nx, M = neq + 2 * T * nu;
+    int n = nx + nu, neq = T * nx, M = neq + T * NINEQ_T;
     REAL cost = 0;
     for (int t = 0; t < T; ++t) {
         REAL a = 0, b = 0;
@@ -97,7 +123,7 @@ static REAL FN(merit_one)(int T, int nx, int nu, const REAL *z, const REAL *res,
  * Hd[T][n][n] (full symmetric blocks), Hs[T-1][n][n] (block (t+1,t); rows >= nx are 0). */
 static void FN(grad_hess_one)(int T, int nx, int nu, const REAL *z, const REAL *res,
                               const REAL *F, const REAL *lam, REAL rho, const REAL *Qd,
-                              const REAL *q, REAL *g, REAL *Hd, REAL *Hs)
+                              const REAL *q, REAL *g, REAL *Hd, REAL *Hs, const REAL *obs)
 {
     int n = nx + nu, neq = T * nx;
     for (int t = 0; t < T; ++t) {
@@ -133,13 +159,26 @@ static void FN(grad_hess_one)(int T, int nx, int nu, const REAL *z, const REAL *
                 for (int b = 0; b < n; ++b) S[r * n + b] = -rho * Ft[r * n + b];
         }
         for (int j = 0; j < nu; ++j) {
-            int ru = neq + t * 2 * nu + j, rl = ru + nu;
+            int ru = neq + t * NINEQ_T + j, rl = ru + nu;
             REAL vu = res[ru], vl = res[rl];
             REAL au = vu >= 0 ? 1 : 0, al = vl >= 0 ? 1 : 0;
             H[(nx + j) * n + nx + j] += rho * (au + al);
             g[t * n + nx + j] += (lam[ru] + rho * (vu > 0 ? vu : 0))
                                - (lam[rl] + rho * (vl > 0 ? vl : 0));
         }
+        /* obstacle rows: J_k = -2 (p - o_k)' on the first three states; g += (lam_k + rho c_k+) J_k',
+         * H += rho J_k'J_k for the rows with c_k >= 0 (al_utils.py:373-386, 113-120) */
+        if (obs)
+            for (int k = 0; k < NOBS; ++k) {
+                int rk = neq + t * NINEQ_T + 2 * nu + k;
+                REAL ck = res[rk], dv[3];
+                for (int a = 0; a < 3; ++a) dv[a] = z[t * n + a] - obs[(t * NOBS + k) * 3 + a];
+                REAL coef = lam[rk] + rho * (ck > 0 ? ck : 0);
+                for (int a = 0; a < 3; ++a) g[t * n + a] += coef * (-2 * dv[a]);
+                if (ck >= 0)
+                    for (int a = 0; a < 3; ++a)
+                        for (int c = 0; c < 3; ++c) H[a * n + c] += rho * 4 * dv[a] * dv[c];
+            }
     }
 }
 
@@ -325,16 +364,16 @@ void FN(orc_grad_hess)(int B, int T, int nx, int nu, const REAL *z, const REAL *
                        const REAL *Qd, const REAL *q, const REAL *ulo, const REAL *uhi,
                        long sb_u, long st_u, REAL *g, REAL *Hd, REAL *Hs)
 {
-    int n = nx + nu, M = T * nx + 2 * T * nu;
+    int n = nx + nu, M = T * nx + T * NINEQ_T;
 #pragma omp parallel for schedule(static)
     for (int b = 0; b < B; ++b) {
         REAL *res = (REAL *)malloc(sizeof(REAL) * M);
         FN(residual_one)(T, nx, nu, z + (long)b * T * n, xnext + (long)b * (T - 1) * nx,
-                         x0 + (long)b * nx, ulo + IDX_U(b), uhi + IDX_U(b), st_u, res);
+                         x0 + (long)b * nx, ulo + IDX_U(b), uhi + IDX_U(b), st_u, res, OBS_OF(b));
         FN(grad_hess_one)(T, nx, nu, z + (long)b * T * n, res, F + (long)b * (T - 1) * nx * n,
                           lam + (long)b * M, rho[b], Qd + (long)b * T * n, q + (long)b * T * n,
                           g + (long)b * T * n, Hd + (long)b * T * n * n,
-                          Hs + (long)b * (T - 1) * n * n);
+                          Hs + (long)b * (T - 1) * n * n, OBS_OF(b));
         free(res);
     }
 }
@@ -382,12 +421,12 @@ void FN(orc_merit)(int B, int T, int nx, int nu, const REAL *z, const REAL *xnex
                    const REAL *q, const REAL *ulo, const REAL *uhi, long sb_u, long st_u,
                    REAL *phi, REAL *rp2)
 {
-    int n = nx + nu, M = T * nx + 2 * T * nu;
+    int n = nx + nu, M = T * nx + T * NINEQ_T;
 #pragma omp parallel for schedule(static)
     for (int b = 0; b < B; ++b) {
         REAL *res = (REAL *)malloc(sizeof(REAL) * M);
         FN(residual_one)(T, nx, nu, z + (long)b * T * n, xnext + (long)b * (T - 1) * nx,
-                         x0 + (long)b * nx, ulo + IDX_U(b), uhi + IDX_U(b), st_u, res);
+                         x0 + (long)b * nx, ulo + IDX_U(b), uhi + IDX_U(b), st_u, res, OBS_OF(b));
         REAL sq;
         phi[b] = FN(merit_one)(T, nx, nu, z + (long)b * T * n, res, lam + (long)b * M, rho[b],
                                Qd + (long)b * T * n, q + (long)b * T * n, &sq);
@@ -422,12 +461,12 @@ void FN(orc_dual_update)(int B, int T, int nx, int nu, const REAL *z, const REAL
                          const REAL *x0, const REAL *ulo, const REAL *uhi, long sb_u,
                          long st_u, REAL *lam, REAL *rho)
 {
-    int n = nx + nu, neq = T * nx, M = neq + 2 * T * nu;
+    int n = nx + nu, neq = T * nx, M = neq + T * NINEQ_T;
 #pragma omp parallel for schedule(static)
     for (int b = 0; b < B; ++b) {
         REAL *res = (REAL *)malloc(sizeof(REAL) * M);
         FN(residual_one)(T, nx, nu, z + (long)b * T * n, xnext + (long)b * (T - 1) * nx,
-                         x0 + (long)b * nx, ulo + IDX_U(b), uhi + IDX_U(b), st_u, res);
+                         x0 + (long)b * nx, ulo + IDX_U(b), uhi + IDX_U(b), st_u, res, OBS_OF(b));
         REAL *l = lam + (long)b * M;
         for (int r = 0; r < M; ++r) {
             REAL v = l[r] + rho[b] * res[r];
@@ -462,7 +501,7 @@ int FN(orc_solve_lin)(int B, int T, int nx, int nu, int al_iter, int max_newton,
                       unsigned char *status, int *newton_per_al, FN(orc_trace) *tr,
                       REAL *Lsave, REAL *zsave)
 {
-    int n = nx + nu, neq = T * nx, M = neq + 2 * T * nu;
+    int n = nx + nu, neq = T * nx, M = neq + T * NINEQ_T;
     long N = (long)T * n, XN = (long)(T - 1) * nx;
     REAL *xnext = (REAL *)malloc(sizeof(REAL) * B * (XN > 0 ? XN : 1));
     REAL *g = (REAL *)malloc(sizeof(REAL) * B * N);

@@ -75,6 +75,30 @@ def set_threads(n):
     lib().orc_set_threads(int(n))
 
 
+_obs_keep = {}
+
+
+class obstacles:
+    """Context manager: the oracle calls inside see `nobs` obstacle rows per stage (Obstacle_MPC):
+    pos [B,T,nobs,3], radius. Process-global C state (orc_set_obstacles), restored on exit."""
+
+    def __init__(self, dtype, pos, radius):
+        self.dtype, self.pos, self.radius = dtype, (None if pos is None else _c(pos, _np(dtype))), float(radius)
+
+    def __enter__(self):
+        fn = getattr(lib(), "orc_set_obstacles_" + self.dtype)
+        if self.pos is None:
+            fn(None, 0, C.c_double(0.0))
+        else:
+            _obs_keep[self.dtype] = self.pos
+            fn(_p(self.pos), int(self.pos.shape[2]), C.c_double(self.radius))
+        return self
+
+    def __exit__(self, *exc):
+        getattr(lib(), "orc_set_obstacles_" + self.dtype)(None, 0, C.c_double(0.0))
+        _obs_keep.pop(self.dtype, None)
+
+
 def grad_hess(dtype, z, xnext, F, x0, lam, rho, Qd, q, ulo, uhi):
     dt = _np(dtype)
     B, T, n = z.shape

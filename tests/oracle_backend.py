@@ -116,12 +116,18 @@ class OracleBackend:
             off += n - i
         return np.linalg.inv(X.transpose(0, 1, 3, 2))
 
+    @staticmethod
+    def _obs(s, obs):
+        """Oracle context for the obstacle rows of Obstacle_MPC (obs = (centres [B,T,nobs,3], radius))."""
+        return orc.obstacles(s, None if obs is None else _n(obs[0]), 0.0 if obs is None else obs[1])
+
     def newton_step(self, dims, z, xnext, F, x0, lam, rho, Qd, q, ulo, uhi, sb_u, st_u, d_out, g_out=None,
-                    factor=None, info=None):
+                    factor=None, info=None, obs=None):
         B, T, nx, nu = dims
         s = _sfx(z)
         lo, hi = _bounds(ulo, uhi, sb_u, st_u, B, T, nu)
-        g, Hd, Hs = orc.grad_hess(s, _n(z), _n(xnext), _n(F), _n(x0), _n(lam), _n(rho), _n(Qd), _n(q), lo, hi)
+        with self._obs(s, obs):
+            g, Hd, Hs = orc.grad_hess(s, _n(z), _n(xnext), _n(F), _n(x0), _n(lam), _n(rho), _n(Qd), _n(q), lo, hi)
         d, inf, L, _ = orc.newton_dir(s, g, Hd, Hs, nx, want_factor=True)
         d_out.copy_(torch.from_numpy(d))
         if g_out is not None:
@@ -132,13 +138,14 @@ class OracleBackend:
             cur = _n(info)
             info.copy_(torch.from_numpy(np.where(cur == 0, inf, cur).astype(np.int32)))
 
-    def merit(self, dims, K, zc, xnext, x0, lam, rho, Qd, q, ulo, uhi, sb_u, st_u, phi, rnorm2=None):
+    def merit(self, dims, K, zc, xnext, x0, lam, rho, Qd, q, ulo, uhi, sb_u, st_u, phi, rnorm2=None, obs=None):
         B, T, nx, nu = dims
         s = _sfx(zc)
         lo, hi = _bounds(ulo, uhi, sb_u, st_u, B, T, nu)
         zc_, xn_ = _n(zc).reshape(K, B, T, nx + nu), _n(xnext).reshape(K, B, T - 1, nx)
         for k in range(K):
-            p, r2 = orc.merit(s, zc_[k], xn_[k], _n(x0), _n(lam), _n(rho), _n(Qd), _n(q), lo, hi)
+            with self._obs(s, obs):
+                p, r2 = orc.merit(s, zc_[k], xn_[k], _n(x0), _n(lam), _n(rho), _n(Qd), _n(q), lo, hi)
             phi.view(K, B)[k].copy_(torch.from_numpy(p))
             if rnorm2 is not None:
                 rnorm2.view(K, B)[k].copy_(torch.from_numpy(r2))
@@ -154,11 +161,12 @@ class OracleBackend:
         if accept_out is not None:
             accept_out.copy_(torch.from_numpy(acc))
 
-    def dual_update(self, dims, z, xnext, x0, ulo, uhi, sb_u, st_u, lam, rho, rho_scale=10.0):
+    def dual_update(self, dims, z, xnext, x0, ulo, uhi, sb_u, st_u, lam, rho, rho_scale=10.0, obs=None):
         B, T, nx, nu = dims
         s = _sfx(z)
         lo, hi = _bounds(ulo, uhi, sb_u, st_u, B, T, nu)
-        ll, rr = orc.dual_update(s, _n(z), _n(xnext), _n(x0), lo, hi, _n(lam), _n(rho))
+        with self._obs(s, obs):
+            ll, rr = orc.dual_update(s, _n(z), _n(xnext), _n(x0), lo, hi, _n(lam), _n(rho))
         lam.copy_(torch.from_numpy(ll))
         rho.copy_(torch.from_numpy(rr))
 
