@@ -225,11 +225,29 @@ class HipBackend:
         return _lib.AlqpObstacles(_ptr(pos, "obstacle centres", dt).value, float(radius), int(pos.shape[2]))
 
     def newton_step(self, dims, z, xnext, F, x0, lam, rho, Qd, q, ulo, uhi, sb_u, st_u, d_out,
-                    g_out=None, factor=None, info=None, obs=None):
+                    g_out=None, factor=None, info=None, obs=None, workspace=None):
+        """workspace: a quad-variant workspace tensor -> alqp_newton_step_ws (16 instances per wavefront,
+        the factor stays in the workspace records for backward_ws); None -> the team kernel
+        (one instance per lane team, optional packed `factor`)."""
         B, T, nx, nu = dims
         dt = z.dtype
         sfx = _dt(z)
         d = _lib.AlqpDims(B, T, nx, nu)
+        if workspace is not None:
+            if obs is not None or factor is not None:
+                raise ValueError("mi_alqp: the quad Newton step takes neither obstacle rows nor a packed factor")
+            need = self.workspace_bytes(*dims, dt)
+            if workspace.numel() * workspace.element_size() < need:
+                raise ValueError("mi_alqp: workspace too small")
+            rc = getattr(self.lib, "alqp_newton_step_ws_" + sfx)(
+                C.byref(d), _ptr(z, "z", dt), _ptr(xnext, "xnext", dt), _ptr(F, "F", dt), _ptr(x0, "x0", dt),
+                _ptr(lam, "lam", dt), _ptr(rho, "rho", dt), _ptr(Qd, "Qd", dt), _ptr(q, "q", dt),
+                _ptr(ulo, "u_lower", dt), _ptr(uhi, "u_upper", dt), sb_u, st_u, _ptr(workspace, "workspace", dt), need,
+                _ptr(d_out, "d_out", dt), _ptr(g_out, "g_out", dt, True), _ptr(info, "info", torch.int32, True), _stream())
+            _lib.check(rc, "alqp_newton_step_ws_" + sfx)
+            self.last_step_kernel = "k_newton_step_quad"
+            return
+        self.last_step_kernel = "k_newton_step"
         head = (C.byref(d), _ptr(z, "z", dt), _ptr(xnext, "xnext", dt), _ptr(F, "F", dt),
                 _ptr(x0, "x0", dt), _ptr(lam, "lam", dt), _ptr(rho, "rho", dt), _ptr(Qd, "Qd", dt),
                 _ptr(q, "q", dt), _ptr(ulo, "u_lower", dt), _ptr(uhi, "u_upper", dt), sb_u, st_u)
@@ -257,6 +275,24 @@ class HipBackend:
             o = self._obs_struct(obs, dims, dt)
             rc = getattr(self.lib, "alqp_merit_obs_" + sfx)(*head, C.byref(o), *tail)
         _lib.check(rc, "alqp_merit_" + sfx)
+
+    def merit_pick(self, dims, n_ls, d, xnext_all, x0, lam, rho, Qd, q, ulo, uhi, sb_u, st_u, z, phi_prev,
+                   rnorm2=None, phi_all=None, k_out=None, accept_out=None, obs=None):
+        """The line search of one Newton step in one launch (alqp_merit_pick): merits of z + 2^-k d from the
+        caller's x_next of every candidate, decision, z and phi_prev updated in place."""
+        B, T, nx, nu = dims
+        dt = z.dtype
+        sfx = _dt(z)
+        dd = _lib.AlqpDims(B, T, nx, nu)
+        o = self._obs_struct(obs, dims, dt) if obs is not None else None
+        rc = getattr(self.lib, "alqp_merit_pick_" + sfx)(
+            C.byref(dd), n_ls, _ptr(d, "d", dt), _ptr(xnext_all, "xnext_all", dt), _ptr(x0, "x0", dt),
+            _ptr(lam, "lam", dt), _ptr(rho, "rho", dt), _ptr(Qd, "Qd", dt), _ptr(q, "q", dt),
+            _ptr(ulo, "u_lower", dt), _ptr(uhi, "u_upper", dt), sb_u, st_u, C.byref(o) if o is not None else None,
+            _ptr(z, "z", dt), _ptr(phi_prev, "phi_prev", dt), _ptr(rnorm2, "rnorm2", dt, True),
+            _ptr(phi_all, "phi_all", dt, True), _ptr(k_out, "k_out", torch.int32, True),
+            _ptr(accept_out, "accept_out", torch.int32, True), _stream())
+        _lib.check(rc, "alqp_merit_pick_" + sfx)
 
     def linesearch_pick(self, dims, n_ls, phi, phi_prev, d, z, k_out=None, accept_out=None):
         B, T, nx, nu = dims

@@ -412,6 +412,68 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     }
 }
 
+// ---- one Newton direction (nonlinear-caller mode), quad variant: 16 instances per wavefront, the
+//      factor streamed through (and left in) the workspace records, like the fused quad solve. The
+//      caller evaluated dx_jac -> (xnext = f(z), F) in PyTorch (al_utils.py:233-248); the sweeps run on the
+//      affine model x+ = F z + c with c = xnext - F z, whose residual at z is the true one.
+template <typename real, int NX, int NU>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_newton_step_quad(StepArgs<real> a, real *ws) {
+    using C = QCfg<real, NX, NU>;
+    constexpr int N = C::N, SW = C::SW;
+    const int lane = threadIdx.x, qi = lane >> 2;
+    const int b_raw = blockIdx.x * 16 + qi;
+    const bool active = b_raw < a.B;
+    const int b = active ? b_raw : a.B - 1;
+    const int T = a.T, M = C::M(T);
+    Quad<real, NX, NU> qd;
+    qd.q = lane & 3;
+    qd.T = T;
+    qd.active = active;
+    qd.gQd = a.Qd + (size_t)b * T * N;
+    qd.gq = a.q + (size_t)b * T * N;
+    qd.gF = a.F + (size_t)b * (T - 1) * NX * N;
+    qd.gc = nullptr;
+    qd.gx0 = a.x0 + (size_t)b * NX;
+    qd.gulo = a.ulo + (size_t)b * a.sb_u;
+    qd.guhi = a.uhi + (size_t)b * a.sb_u;
+    qd.st_u = a.st_u;
+    qd.gz = const_cast<real *>(a.z) + (size_t)b * T * N;        // read-only here
+    qd.glam = const_cast<real *>(a.lam) + (size_t)b * M;        // read-only here
+    qd.rec = ws + (size_t)b * T * C::RECW;
+    qd.gFw = const_cast<real *>(qd.gF);
+    qd.dyn_h = 0;
+    qd.rho = a.rho[b];
+    qd.info = 0;
+    qd.stage_in(false, false);
+    // c_t = xnext_t - F_t z_t into the records (own rows 4s+q)
+    const real *gxn = a.xnext + (size_t)b * (T - 1) * NX;
+    for (int t = 0; t < T - 1; ++t) {
+        real W[SW][N], zt[N];
+        qd.load_F_rows(t, W);
+        gload<N>(qd.gz + t * N, zt);
+#pragma unroll
+        for (int s = 0; s < SW; ++s) {
+            const int r = 4 * s + qd.q;
+            if ((4 * s + 3 < NX || r < NX) && active) {
+                real cv = gxn[t * NX + r];
+#pragma unroll
+                for (int k = 0; k < N; ++k) cv = fma_(-W[s][k], zt[k], cv);
+                qd.recp(t)[C::oC + r] = cv;
+            }
+        }
+    }
+    real *tg = (a.g_out && active) ? a.g_out + (size_t)b * T * N : nullptr;
+    qd.forward(tg, real(0), false, nullptr);
+    real unused[20];
+    qd.template backward<false>(unused);
+    if (active) {
+        real *gd = a.d_out + (size_t)b * T * N;
+        for (int t = 0; t < T; ++t)
+            for (int j = qd.q; j < N; j += 4) gd[t * N + j] = qd.recp(t)[C::oY + j];
+        if (qd.q == 0 && a.info && qd.info && a.info[b] == 0) a.info[b] = qd.info;
+    }
+}
+
 #endif  // ALQP_BUILD_QUAD
 
 #if ALQP_BUILD_MAIN
@@ -576,6 +638,110 @@ __global__ __launch_bounds__(64) void k_merit(AuxArgs<real> a) {
     }
 }
 
+// The whole line search of one Newton step in ONE launch (nonlinear-caller mode at scale): the merits of
+// the n_ls candidates z + 2^-k d (al_utils.py:618-633; x_next of every candidate was evaluated by the
+// caller's dynamics: xnext_all [n_ls][B][T-1][nx]), first-argmin with NaN winning like torch.min, strict
+// accept, z <- z + alpha d in place, phi_prev <- phi_min regardless (:569), rnorm2 <- sum r+^2 of the
+// chosen candidate when accepted. One wavefront per instance: it reads z, d once (not the 20-fold stack
+// the reference materialises) and its 20 x_next slabs; everything else comes from registers.
+template <typename real>
+__global__ __launch_bounds__(64) void k_merit_pick(AuxArgs<real> a) {
+    const int lane = threadIdx.x, b = blockIdx.x;
+    const int T = a.T, nx = a.nx, nu = a.nu, n = nx + nu, neq = T * nx, nit = 2 * nu + a.nobs;
+    real *z = a.z + (size_t)b * T * n;
+    const real *d = a.d + (size_t)b * T * n;
+    const real *lam = a.lam + (size_t)b * (neq + T * nit);
+    const real *Qd = a.Qd + (size_t)b * T * n, *q = a.q + (size_t)b * T * n;
+    const real *ulo = a.ulo + (size_t)b * a.sb_u, *uhi = a.uhi + (size_t)b * a.sb_u;
+    const real rho = a.rho[b];
+    real acc[20], sq[20];
+#pragma unroll
+    for (int k = 0; k < 20; ++k) { acc[k] = 0; sq[k] = 0; }
+    // cost + bound rows: every lane walks its elements once, all candidates from registers
+    for (int e = lane; e < T * n; e += 64) {
+        const int t = e / n, j = e - t * n;
+        const real zv = z[e], dv = d[e], Qv = Qd[e], qv = q[e];
+        real bu = 0, bl = 0, lu = 0, ll = 0;
+        const bool isu = j >= nx;
+        if (isu) {
+            bu = uhi[t * a.st_u + j - nx]; bl = ulo[t * a.st_u + j - nx];
+            lu = lam[neq + t * nit + j - nx]; ll = lam[neq + t * nit + nu + j - nx];
+        }
+        real alpha = 1;
+#pragma unroll
+        for (int k = 0; k < 20; ++k) {
+            const real v = zv + alpha * dv;
+            acc[k] += (real(0.5) * Qv * v + qv) * v;
+            if (isu) {
+                const real vu = v - bu, vl = -v + bl;
+                const real cu = vu > 0 ? vu : real(0), cl = vl > 0 ? vl : real(0);
+                acc[k] += lu * vu + ll * vl;
+                sq[k] += cu * cu + cl * cl;
+            }
+            alpha *= real(0.5);
+        }
+    }
+    // equality rows: r = x_{t+1}(candidate) - xnext_k, init rows x_0 - x0
+    for (int e = lane; e < neq; e += 64) {
+        const int t = e / nx, i = e - t * nx;
+        const real le = lam[e];
+        const int zi = (t < T - 1) ? (t + 1) * n + i : i;
+        const real zv = z[zi], dv = d[zi];
+        const real x0v = (t < T - 1) ? real(0) : a.x0[(size_t)b * nx + i];
+        real alpha = 1;
+#pragma unroll
+        for (int k = 0; k < 20; ++k) {
+            if (k < a.n_ls) {
+                const real ref = (t < T - 1) ? a.xnext[(((size_t)k * a.B + b) * (T - 1) + t) * nx + i] : x0v;
+                const real r = zv + alpha * dv - ref;
+                acc[k] += le * r;
+                sq[k] += r * r;
+            }
+            alpha *= real(0.5);
+        }
+    }
+    // obstacle rows (Obstacle_MPC): c_k at the candidate's position
+    for (int e = lane; e < T * a.nobs; e += 64) {
+        const int t = e / a.nobs;
+        const real *o = a.obs + ((size_t)b * T * a.nobs + e) * 3;
+        const real lk = lam[neq + t * nit + 2 * nu + e % a.nobs];
+        real alpha = 1;
+#pragma unroll
+        for (int k = 0; k < 20; ++k) {
+            const real d0 = z[t * n] + alpha * d[t * n] - o[0], d1 = z[t * n + 1] + alpha * d[t * n + 1] - o[1],
+                       d2 = z[t * n + 2] + alpha * d[t * n + 2] - o[2];
+            const real ck = a.obs_r2 - (d0 * d0 + d1 * d1 + d2 * d2), cp = ck > 0 ? ck : real(0);
+            acc[k] += lk * ck;
+            sq[k] += cp * cp;
+            alpha *= real(0.5);
+        }
+    }
+    int kbest = 0;
+    real best = 0, sqbest = 0;
+#pragma unroll
+    for (int k = 0; k < 20; ++k) {
+        if (k < a.n_ls) {
+            const real s2 = wave_sum(sq[k]);
+            const real v = wave_sum(acc[k]) + real(0.5) * rho * s2;
+            if (a.phi) a.phi[(size_t)k * a.B + b] = v;     // (all lanes hold the same value)
+            if (k == 0) { best = v; sqbest = s2; }
+            else if (!(best != best) && (v != v || v < best)) { best = v; kbest = k; sqbest = s2; }
+        }
+    }
+    const real prev = a.phi_prev[b];
+    const bool ok = best < prev;
+    if (ok) {
+        const real alpha = real(1) / real(1 << kbest);
+        for (int e = lane; e < T * n; e += 64) z[e] += alpha * d[e];
+    }
+    if (lane == 0) {
+        a.phi_prev[b] = best;
+        if (a.k_out) a.k_out[b] = kbest;
+        if (a.accept_out) a.accept_out[b] = ok ? 1 : 0;
+        if (a.rnorm2 && ok) a.rnorm2[b] = sqbest;
+    }
+}
+
 // line-search decision + update (al_utils.py:634-641), block = instance
 template <typename real>
 __global__ __launch_bounds__(64) void k_pick(AuxArgs<real> a) {
@@ -688,6 +854,8 @@ template <typename real>
 int dispatch_backward_quad(int nx, int nu, const BwdArgs<real> &a, real *ws, hipStream_t stream);
 template <typename real>
 int dispatch_solve_nonlin(int dyn_id, int nx, int nu, const SolveArgs<real> &a, real *ws, hipStream_t stream);
+template <typename real>
+int dispatch_step_quad(int nx, int nu, const StepArgs<real> &a, real *ws, hipStream_t stream);
 
 #if ALQP_BUILD_QUAD
 template <typename real, int NX, int NU, typename Fn, typename... Args>
@@ -733,6 +901,22 @@ int dispatch_solve_nonlin(int dyn_id, int nx, int nu, const SolveArgs<real> &a, 
                                               TraceArgs<real>{}, ws);
     return ALQP_E_UNSUPPORTED;
 }
+
+template <typename real>
+int dispatch_step_quad(int nx, int nu, const StepArgs<real> &a, real *ws, hipStream_t stream) {
+#define X(NX, NU) \
+    if (nx == NX && nu == NU) return launch_quad_kernel<real, NX, NU>(k_newton_step_quad<real, NX, NU>, a.B, stream, a, ws);
+    ALQP_FOR_EACH_DIMS(X)
+#undef X
+    return ALQP_E_UNSUPPORTED;
+}
+
+#if ALQP_QUAD_F32
+template int dispatch_step_quad<float>(int, int, const StepArgs<float> &, float *, hipStream_t);
+#endif
+#if ALQP_QUAD_F64
+template int dispatch_step_quad<double>(int, int, const StepArgs<double> &, double *, hipStream_t);
+#endif
 
 #if ALQP_QUAD_F32
 template int dispatch_solve_nonlin<float>(int, int, int, const SolveArgs<float> &, float *, hipStream_t);
@@ -875,7 +1059,8 @@ template <typename real>
 int newton_step_impl(const AlqpDims *dims, const void *z, const void *xnext, const void *F,
                      const void *x0, const void *lam, const void *rho, const void *Qd, const void *q,
                      const void *u_lo, const void *u_hi, long sb_u, long st_u, void *d_out,
-                     void *g_out, void *factor_out, int *info, void *stream, const AlqpObstacles *obs = nullptr) {
+                     void *g_out, void *factor_out, int *info, void *stream, const AlqpObstacles *obs = nullptr,
+                     void *workspace = nullptr, size_t ws_bytes = 0) {
     if (!dims_ok(dims) || !z || !xnext || !F || !x0 || !lam || !rho || !Qd || !q || !u_lo || !u_hi || !d_out)
         return ALQP_E_BADARG;
     if (obs && (obs->nobs < 0 || (obs->nobs > 0 && (!obs->pos || dims->nx < 3)))) return ALQP_E_BADARG;
@@ -886,6 +1071,13 @@ int newton_step_impl(const AlqpDims *dims, const void *z, const void *xnext, con
     a.lam = (const real *)lam; a.rho = (const real *)rho; a.Qd = (const real *)Qd; a.q = (const real *)q;
     a.ulo = (const real *)u_lo; a.uhi = (const real *)u_hi; a.sb_u = sb_u; a.st_u = st_u;
     a.d_out = (real *)d_out; a.g_out = (real *)g_out; a.factor = (real *)factor_out; a.info = info;
+    if (workspace) {   // quad variant: the factor stays in the workspace records (alqp_backward_ws)
+        if (a.nobs > 0 || factor_out) return ALQP_E_BADARG;
+        const size_t need = quad_ws_bytes<real>(dims->nx, dims->nu, dims->B, dims->T);
+        if (need == 0) return ALQP_E_UNSUPPORTED;
+        if (ws_bytes < need) return ALQP_E_BADARG;
+        return dispatch_step_quad<real>(dims->nx, dims->nu, a, (real *)workspace, (hipStream_t)stream);
+    }
     return dispatch_step<real>(dims->nx, dims->nu, a, (hipStream_t)stream);
 }
 
@@ -935,6 +1127,27 @@ int merit_impl(const AlqpDims *dims, int K, const void *zc, const void *xnext, c
     a.phi = (real *)phi; a.rnorm2 = (real *)rnorm2;
     hipLaunchKernelGGL(k_merit<real>, dim3((unsigned)((size_t)K * dims->B)), dim3(64), 0,
                        (hipStream_t)stream, a);
+    return hipGetLastError() == hipSuccess ? 0 : ALQP_E_LAUNCH;
+}
+
+template <typename real>
+int merit_pick_impl(const AlqpDims *dims, int n_ls, const void *d, const void *xnext_all, const void *x0,
+                    const void *lam, const void *rho, const void *Qd, const void *q, const void *u_lo,
+                    const void *u_hi, long sb_u, long st_u, const AlqpObstacles *obs, void *z, void *phi_prev,
+                    void *rnorm2, void *phi_all, int *k_out, int *accept_out, void *stream) {
+    if (!dims_ok(dims) || n_ls < 1 || n_ls > 20 || !d || !xnext_all || !x0 || !lam || !rho || !Qd || !q || !u_lo ||
+        !u_hi || !z || !phi_prev)
+        return ALQP_E_BADARG;
+    if (obs && (obs->nobs < 0 || (obs->nobs > 0 && (!obs->pos || dims->nx < 3)))) return ALQP_E_BADARG;
+    AuxArgs<real> a = {};
+    if (obs && obs->nobs > 0) { a.obs = (const real *)obs->pos; a.nobs = obs->nobs; a.obs_r2 = (real)(obs->radius * obs->radius); }
+    a.B = dims->B; a.T = dims->T; a.nx = dims->nx; a.nu = dims->nu; a.n_ls = n_ls;
+    a.d = (const real *)d; a.xnext = (const real *)xnext_all; a.x0 = (const real *)x0;
+    a.lam = (const real *)lam; a.rho = (const real *)rho; a.Qd = (const real *)Qd; a.q = (const real *)q;
+    a.ulo = (const real *)u_lo; a.uhi = (const real *)u_hi; a.sb_u = sb_u; a.st_u = st_u;
+    a.z = (real *)z; a.phi_prev = (real *)phi_prev; a.rnorm2 = (real *)rnorm2; a.phi = (real *)phi_all;
+    a.k_out = k_out; a.accept_out = accept_out;
+    hipLaunchKernelGGL(k_merit_pick<real>, dim3(dims->B), dim3(64), 0, (hipStream_t)stream, a);
     return hipGetLastError() == hipSuccess ? 0 : ALQP_E_LAUNCH;
 }
 
@@ -1339,6 +1552,32 @@ ALQP_DEFINE(f64, double)
 
 ALQP_DEFINE_OBS(f32, float)
 ALQP_DEFINE_OBS(f64, double)
+
+#define ALQP_DEFINE_STEP_WS(SFX, REAL)                                                                \
+    int alqp_newton_step_ws_##SFX(const AlqpDims *dims, const void *z, const void *xnext, const void *F, \
+                                  const void *x0, const void *lam, const void *rho, const void *Qd,   \
+                                  const void *q, const void *u_lo, const void *u_hi, long sb_u,       \
+                                  long st_u, void *workspace, size_t ws_bytes, void *d_out,           \
+                                  void *g_out, int *info, void *stream) {                             \
+        if (!workspace) return ALQP_E_BADARG;                                                         \
+        return alqp::newton_step_impl<REAL>(dims, z, xnext, F, x0, lam, rho, Qd, q, u_lo, u_hi, sb_u, \
+                                            st_u, d_out, g_out, nullptr, info, stream, nullptr,       \
+                                            workspace, ws_bytes);                                     \
+    }
+#define ALQP_DEFINE_MERIT_PICK(SFX, REAL)                                                             \
+    int alqp_merit_pick_##SFX(const AlqpDims *dims, int n_ls, const void *d, const void *xnext_all,   \
+                              const void *x0, const void *lam, const void *rho, const void *Qd,       \
+                              const void *q, const void *u_lo, const void *u_hi, long sb_u, long st_u, \
+                              const AlqpObstacles *obs, void *z, void *phi_prev, void *rnorm2,        \
+                              void *phi_all, int *k_out, int *accept_out, void *stream) {             \
+        return alqp::merit_pick_impl<REAL>(dims, n_ls, d, xnext_all, x0, lam, rho, Qd, q, u_lo, u_hi, \
+                                           sb_u, st_u, obs, z, phi_prev, rnorm2, phi_all, k_out,      \
+                                           accept_out, stream);                                       \
+    }
+ALQP_DEFINE_MERIT_PICK(f32, float)
+ALQP_DEFINE_MERIT_PICK(f64, double)
+ALQP_DEFINE_STEP_WS(f32, float)
+ALQP_DEFINE_STEP_WS(f64, double)
 
 int alqp_backward_ws_f32(const AlqpDims *dims, void *workspace, size_t ws_bytes, const void *F,
                          const void *rho, const void *z_final, const void *gbar, void *q_grad,

@@ -469,19 +469,25 @@ class MPC(Module):
         while steps < MAX_NEWTON:
             steps += 1
             xn, F = self._linearize(st, z)
-            be.newton_step(dims, z, xn, F, st.x0, st.lam, st.rho, Qd, q, lo, hi, sb, stt, ws["d"],
-                           factor=ws.get("factor") if need_factor else None, info=ws["info"], **okw)
+            # from B = QUAD_MIN_BATCH on (and without obstacle rows) the direction comes from the quad kernels,
+            # whose factor stays in the workspace records: a private one (ws["qws"]) when backward follows
+            qws = ws.get("qws")
+            if qws is None and not okw and hasattr(be, "_workspace") and B >= getattr(be, "QUAD_MIN_BATCH", 1 << 62):
+                qws = be._workspace(dims, z)[0]
+            if qws is not None:
+                be.newton_step(dims, z, xn, F, st.x0, st.lam, st.rho, Qd, q, lo, hi, sb, stt, ws["d"],
+                               info=ws["info"], workspace=qws)
+            else:
+                be.newton_step(dims, z, xn, F, st.x0, st.lam, st.rho, Qd, q, lo, hi, sb, stt, ws["d"],
+                               factor=ws.get("factor") if need_factor else None, info=ws["info"], **okw)
             if need_factor:
                 ws["F_last"] = F
             zc = (z.unsqueeze(0) + alphas * ws["d"].unsqueeze(0)).contiguous()
             xnc = dyn(zc)
-            be.merit(dims, N_LS, zc, xnc, st.x0, st.lam, st.rho, Qd, q, lo, hi, sb, stt,
-                     ws["phis"], ws["rn2s"], **okw)
-            be.linesearch_pick(dims, N_LS, ws["phis"], ws["phi"], ws["d"], z, ws["k"], ws["acc"])
+            # 20 merits + decision + update in one launch; rn2 <- the chosen candidate's when accepted
+            be.merit_pick(dims, N_LS, ws["d"], xnc, st.x0, st.lam, st.rho, Qd, q, lo, hi, sb, stt, z, ws["phi"],
+                          rnorm2=ws["rn2"], k_out=ws["k"], accept_out=ws["acc"], **okw)
             if self.exit_mode == "reference":
-                rn2 = torch.where(ws["acc"].bool(), ws["rn2s"].gather(0, ws["k"].long().unsqueeze(0)).squeeze(0),
-                                  ws["rn2"])
-                ws["rn2"].copy_(rn2)
                 new = self._global_norm(ws["rn2"])
                 if new < 1e-3 or abs(old - new) / new < 1e-3:
                     break
@@ -510,8 +516,9 @@ class MPC(Module):
             # autograd rejects it, so the reference cannot differentiate this route. Same error type.
             raise RuntimeError("MPC: the linearize_once streaming route is not differentiable (the reference's "
                                "al_utils_lin.NewtonAL.backward returns an incorrect number of gradients)")
+        has_obs = bool(self._obs_kwargs(dt, dev))
         use_qws = need_grad and hasattr(be, "backward_ws") and B >= getattr(be, "QUAD_MIN_BATCH", 0) and (
-            lin is not None)
+            lin is not None or not has_obs) and not (bool(self.linearize_once) and st.stream_mode)
         if use_qws:
             ws["qws"] = be.new_workspace(dims, st.z)
         elif need_grad:
@@ -524,7 +531,6 @@ class MPC(Module):
             raise TypeError("MPC: linearize_once is only defined for the streaming route (after "
                             "warm_start_initialize); the reference's al_solve raises TypeError on it as well")
         linearize_once = bool(self.linearize_once) and stream
-        has_obs = bool(self._obs_kwargs(dt, dev))
         if has_obs and linearize_once:
             raise NotImplementedError("Obstacle_MPC with linearize_once: the reference's frozen-linearisation "
                                       "module knows no obstacle rows (AL_mpc_custom.py:68, 75, 83)")

@@ -45,6 +45,13 @@ typedef struct AlqpDims {
     int nu;  /* control dim */
 } AlqpDims;
 
+/* obstacle rows of Obstacle_MPC (documented with alqp_newton_step_obs_* below) */
+typedef struct AlqpObstacles {
+    const void *pos;   /* DEVICE [B][T][nobs][3], the real type of the call */
+    double radius;
+    int nobs;          /* reference: 4 nearest of 40 (AL_mpc_custom.py:52-54, 112-115) */
+} AlqpObstacles;
+
 /* flags for alqp_solve_lin_* */
 #define ALQP_INIT_MERIT   1  /* evaluate merit(z) at the start of every AL iteration (al_utils.py:481) */
 #define ALQP_DUAL_UPDATE  2  /* lam += rho*r, clamp, rho *= rho_scale after the Newton steps (AL_mpc.py:315-325) */
@@ -136,6 +143,20 @@ int alqp_newton_step_f64(const AlqpDims *dims, const void *z, const void *xnext,
                          void *d_out, void *g_out, void *factor_out, int *info, void *stream);
 
 /*
+ * The same Newton direction by the quad kernels (16 instances per wavefront; use it once the batch fills the
+ * chip, B >= 4096): the per-stage factor is streamed through - and left in - `workspace`
+ * (alqp_workspace_bytes()), where alqp_backward_ws_* finds it for NewtonAL.backward. No packed factor_out.
+ */
+int alqp_newton_step_ws_f32(const AlqpDims *dims, const void *z, const void *xnext, const void *F,
+                            const void *x0, const void *lam, const void *rho, const void *Qd, const void *q,
+                            const void *u_lo, const void *u_hi, long sb_u, long st_u, void *workspace,
+                            size_t ws_bytes, void *d_out, void *g_out, int *info, void *stream);
+int alqp_newton_step_ws_f64(const AlqpDims *dims, const void *z, const void *xnext, const void *F,
+                            const void *x0, const void *lam, const void *rho, const void *Qd, const void *q,
+                            const void *u_lo, const void *u_hi, long sb_u, long st_u, void *workspace,
+                            size_t ws_bytes, void *d_out, void *g_out, int *info, void *stream);
+
+/*
  * Merit of K stacked candidates (al_utils.py:52-77 with the [K,B,T,n] broadcast of
  * :56-70): zc[K][B][T][n], xnext[K][B][T-1][nx] -> phi[K][B], rnorm2[K][B] (nullable).
  */
@@ -157,6 +178,24 @@ int alqp_linesearch_pick_f32(const AlqpDims *dims, int n_ls, const void *phi, vo
                              const void *d, void *z, int *k_out, int *accept_out, void *stream);
 int alqp_linesearch_pick_f64(const AlqpDims *dims, int n_ls, const void *phi, void *phi_prev,
                              const void *d, void *z, int *k_out, int *accept_out, void *stream);
+
+/*
+ * The whole line search of a Newton step in one launch (nonlinear-caller mode at scale): merits of the
+ * n_ls candidates z + 2^-k d, given x_next of every candidate from the caller's dynamics
+ * (xnext_all[n_ls][B][T-1][nx], what the reference's 20-fold replicated dx call returns,
+ * al_utils.py:56-70, 629-633), then the decision and update of alqp_linesearch_pick. z, d are read
+ * once; the stacked candidates the reference materialises are never formed for the merit.
+ *   in/out: z, phi_prev; rnorm2[B] (nullable) <- sum r+^2 of the chosen candidate when accepted
+ *   out   : phi_all[n_ls][B] (nullable), k_out, accept_out (nullable); obs nullable (Obstacle_MPC rows)
+ */
+int alqp_merit_pick_f32(const AlqpDims *dims, int n_ls, const void *d, const void *xnext_all, const void *x0,
+                        const void *lam, const void *rho, const void *Qd, const void *q, const void *u_lo,
+                        const void *u_hi, long sb_u, long st_u, const AlqpObstacles *obs, void *z,
+                        void *phi_prev, void *rnorm2, void *phi_all, int *k_out, int *accept_out, void *stream);
+int alqp_merit_pick_f64(const AlqpDims *dims, int n_ls, const void *d, const void *xnext_all, const void *x0,
+                        const void *lam, const void *rho, const void *Qd, const void *q, const void *u_lo,
+                        const void *u_hi, long sb_u, long st_u, const AlqpObstacles *obs, void *z,
+                        void *phi_prev, void *rnorm2, void *phi_all, int *k_out, int *accept_out, void *stream);
 
 /*
  * Dual update + projection + penalty growth (AL_mpc.py:315-317, 325) given
@@ -265,11 +304,6 @@ int alqp_solve_nonlin_f64(const AlqpDims *dims, const AlqpParams *prm, int dyn_i
  * These are the nonlinear-caller building blocks with obstacles (the reference only reaches Obstacle_MPC
  * with PyTorch-coded dynamics); arguments as their plain twins. nx >= 3 required.
  */
-typedef struct AlqpObstacles {
-    const void *pos;   /* DEVICE [B][T][nobs][3], the real type of the call */
-    double radius;
-    int nobs;          /* reference: 4 nearest of 40 (AL_mpc_custom.py:52-54, 112-115) */
-} AlqpObstacles;
 
 int alqp_newton_step_obs_f32(const AlqpDims *dims, const void *z, const void *xnext, const void *F,
                              const void *x0, const void *lam, const void *rho, const void *Qd, const void *q,

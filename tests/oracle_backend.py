@@ -122,7 +122,7 @@ class OracleBackend:
         return orc.obstacles(s, None if obs is None else _n(obs[0]), 0.0 if obs is None else obs[1])
 
     def newton_step(self, dims, z, xnext, F, x0, lam, rho, Qd, q, ulo, uhi, sb_u, st_u, d_out, g_out=None,
-                    factor=None, info=None, obs=None):
+                    factor=None, info=None, obs=None, workspace=None):
         B, T, nx, nu = dims
         s = _sfx(z)
         lo, hi = _bounds(ulo, uhi, sb_u, st_u, B, T, nu)
@@ -149,6 +149,27 @@ class OracleBackend:
             phi.view(K, B)[k].copy_(torch.from_numpy(p))
             if rnorm2 is not None:
                 rnorm2.view(K, B)[k].copy_(torch.from_numpy(r2))
+
+    def merit_pick(self, dims, n_ls, d, xnext_all, x0, lam, rho, Qd, q, ulo, uhi, sb_u, st_u, z, phi_prev,
+                   rnorm2=None, phi_all=None, k_out=None, accept_out=None, obs=None):
+        """CPU twin of alqp_merit_pick: merits of z + 2^-k d, then linesearch_pick."""
+        B, T, nx, nu = dims
+        alphas = (2.0 ** -torch.arange(n_ls, dtype=z.dtype)).view(n_ls, 1, 1, 1)
+        zc = (z.unsqueeze(0) + alphas * d.unsqueeze(0)).contiguous()
+        phis = torch.empty(n_ls, B, dtype=z.dtype)
+        rn2s = torch.empty(n_ls, B, dtype=z.dtype)
+        self.merit(dims, n_ls, zc, xnext_all, x0, lam, rho, Qd, q, ulo, uhi, sb_u, st_u, phis, rn2s, obs=obs)
+        kk = torch.zeros(B, dtype=torch.int32)
+        acc = torch.zeros(B, dtype=torch.int32)
+        self.linesearch_pick(dims, n_ls, phis, phi_prev, d, z, kk, acc)
+        if rnorm2 is not None:
+            rnorm2.copy_(torch.where(acc.bool(), rn2s.gather(0, kk.long().unsqueeze(0)).squeeze(0), rnorm2))
+        if phi_all is not None:
+            phi_all.copy_(phis)
+        if k_out is not None:
+            k_out.copy_(kk)
+        if accept_out is not None:
+            accept_out.copy_(acc)
 
     def linesearch_pick(self, dims, n_ls, phi, phi_prev, d, z, k_out=None, accept_out=None):
         s = _sfx(z)
