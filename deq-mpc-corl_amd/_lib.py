@@ -88,6 +88,7 @@ _SIGS = {
 _PLAIN = {
     "alqp_abi_version": (C.c_int, []),
     "alqp_supported": (C.c_int, [C.POINTER(AlqpDims), C.c_int]),
+    "alqp_supported_variant": (C.c_int, [C.POINTER(AlqpDims), C.c_int, C.c_int]),
     "alqp_lds_bytes": (C.c_size_t, [C.POINTER(AlqpDims), C.c_int]),
     "alqp_qps_per_wave": (C.c_int, [C.POINTER(AlqpDims), C.c_int]),
     "alqp_workspace_bytes": (C.c_size_t, [C.POINTER(AlqpDims), C.c_int]),

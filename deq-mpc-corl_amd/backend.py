@@ -101,6 +101,8 @@ class HipBackend:
         vnum = {"auto": 0, "team": 1, "quad": 2}[variant]
         if vnum == 0:
             vnum = 1 if ((flags & _lib.ALQP_SAVE_FACTOR) or B < self.QUAD_MIN_BATCH) else 2
+            if vnum == 1 and not (flags & _lib.ALQP_SAVE_FACTOR) and not self.lib.alqp_supported_variant(C.byref(d), int(dt == torch.float64), 1):
+                vnum = 2   # horizon too long for the team's LDS image: the quad kernels run it at any batch
         ws, ws_bytes = (None, 0)
         if vnum == 2:
             if workspace is not None:

@@ -1008,8 +1008,13 @@ int solve_lin_impl(const AlqpDims *dims, const AlqpParams *prm, const void *Qd, 
     int variant = prm->variant;
     // auto: quad once the batch fills the chip (16 instances per wavefront, 1024 SIMDs), team below
     // (2-2.4x lower latency at small batches; measured crossover at (13,4) T=20: B = 4096)
-    if (variant == 0)
-        variant = (need > 0 && workspace && ws_bytes >= need && !(prm->flags & ALQP_SAVE_FACTOR) && dims->B >= 4096) ? 2 : 1;
+    if (variant == 0) {
+        const size_t team_lds = lds_query<real>(dims->nx, dims->nu, dims->T);
+        const bool team_fits = team_lds > 0 && team_lds <= kMaxLds;
+        const bool quad_ok = need > 0 && workspace && ws_bytes >= need && !(prm->flags & ALQP_SAVE_FACTOR);
+        // long horizons whose factor does not fit the team's LDS image run on the quad kernels at any batch
+        variant = (quad_ok && (dims->B >= 4096 || !team_fits)) ? 2 : 1;
+    }
     if (variant == 2) {
         if (prm->flags & ALQP_SAVE_FACTOR) return ALQP_E_UNSUPPORTED;
         if (need == 0) return ALQP_E_UNSUPPORTED;
@@ -1469,8 +1474,18 @@ size_t alqp_lds_bytes(const AlqpDims *dims, int is_f64) {
 }
 
 int alqp_supported(const AlqpDims *dims, int is_f64) {
-    size_t v = alqp_lds_bytes(dims, is_f64);
-    return v > 0 && v <= alqp::kMaxLds;
+    // an (nx, nu) instance exists: the quad variant (HBM workspace) runs any horizon; the team variant
+    // additionally needs its LDS image to fit (alqp_supported_variant)
+    return alqp_workspace_bytes(dims, is_f64) > 0;
+}
+
+int alqp_supported_variant(const AlqpDims *dims, int is_f64, int variant) {
+    if (variant == 2) return alqp_workspace_bytes(dims, is_f64) > 0;
+    if (variant == 1) {
+        size_t v = alqp_lds_bytes(dims, is_f64);
+        return v > 0 && v <= alqp::kMaxLds;
+    }
+    return 0;
 }
 
 int alqp_qps_per_wave(const AlqpDims *dims, int is_f64) {

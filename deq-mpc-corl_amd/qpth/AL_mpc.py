@@ -118,7 +118,8 @@ class MPC(Module):
                  detach_unconverged=True, backprop=True, slew_rate_penalty=None,
                  solver_type="dense", add_goal_constraint=False, x_goal=None, diag_cost=True,
                  ineqG=None, ineqh=None, state_estimator=False, dtype=torch.float64,
-                 exit_mode="reference", backend=None, process_group=None, prefer_fused=False):
+                 exit_mode="reference", backend=None, process_group=None, prefer_fused=False,
+                 check_numerics=None):
         super().__init__()
         if (u_lower is None) != (u_upper is None) or u_lower is None:
             raise ValueError("MPC: u_lower and u_upper are both required (AL_mpc.py:145,152)")
@@ -148,6 +149,13 @@ class MPC(Module):
         self.rho_max = 1e8
         self.dyn_res_prev = 1000000
         self.exit_mode = exit_mode
+        # None: numerical trouble is only recorded (last_info / last_status, no host read-back in the call);
+        # "warn" / "raise": one read-back per call, warnings.warn / FloatingPointError when an instance met a
+        # non-positive pivot (info) or holds a non-finite iterate (status). The reference has no such report:
+        # its cholesky_ex `info` is dropped (al_utils.py:510).
+        if check_numerics not in (None, "warn", "raise"):
+            raise ValueError("check_numerics must be None, 'warn' or 'raise'")
+        self.check_numerics = check_numerics
         self.prefer_fused = bool(prefer_fused)  # take the compiled-in dynamics model even where it is not the default
         self.process_group = process_group
         self._backend = backend
@@ -659,6 +667,17 @@ class MPC(Module):
         self.last_status = ws["status"].bool()
         self.last_info = ws["info"]
         self.dyn_res_prev = ws["rn2"].sqrt()
+        if self.check_numerics is not None:
+            n_piv = int((ws["info"] != 0).sum().item())
+            n_bad = int((ws["status"] == 0).sum().item())
+            if n_piv or n_bad:
+                msg = (f"mi_alqp: {n_piv} of {B} instances met a non-positive pivot (penalty x conditioning beyond "
+                       f"{dt}; modified-Cholesky step taken, see MPC.last_info), {n_bad} hold a non-finite iterate "
+                       "(MPC.last_status)")
+                if self.check_numerics == "raise":
+                    raise FloatingPointError(msg)
+                import warnings
+                warnings.warn(msg, RuntimeWarning, stacklevel=3)
         if need_grad and F_last is not None:
             if "nlws" in ws:
                 return "workspace", ws["nlws"], F_last, rho_last

@@ -88,8 +88,11 @@ typedef struct AlqpTrace {
 #define ALQP_E_UNSUPPORTED (-2)  /* (nx,nu) not instantiated or LDS budget exceeded */
 #define ALQP_E_LAUNCH     (-3)
 
-/* 1 if (nx,nu) has a compiled kernel instance and the horizon fits in LDS. */
+/* 1 if (nx,nu) has a compiled kernel instance (the quad variant then runs any horizon). */
 int alqp_supported(const AlqpDims *dims, int is_f64);
+/* Per variant (AlqpParams.variant): 1 team - additionally the horizon's factor must fit the LDS image;
+ * 2 quad - needs alqp_workspace_bytes() of workspace, no LDS. */
+int alqp_supported_variant(const AlqpDims *dims, int is_f64, int variant);
 /* LDS bytes one workgroup of the fused kernel uses (0 if unsupported). */
 size_t alqp_lds_bytes(const AlqpDims *dims, int is_f64);
 /* QP instances one 64-lane wavefront solves concurrently (team variant). */

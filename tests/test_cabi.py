@@ -36,7 +36,10 @@ def test_supported_dims_and_lds_budget():
     assert q(65536, 50, 13, 4) == (1, 1)
     assert q(4, 20, 7, 3) == (0, 0)            # not instantiated
     assert q(4, 1, 13, 4) == (0, 0)            # T < 2
-    assert q(4, 400, 13, 4) == (0, 0)          # horizon does not fit 160 KiB of LDS
+    assert q(4, 400, 13, 4) == (1, 1)          # too long for the team's LDS image, but the quad variant runs it
+    v = lambda var, *d: lib.alqp_supported_variant(C.byref(_lib.AlqpDims(*d)), 0, var)
+    assert v(1, 4, 400, 13, 4) == 0 and v(2, 4, 400, 13, 4) == 1
+    assert v(1, 4, 20, 13, 4) == 1 and v(2, 4, 20, 13, 4) == 1 and v(3, 4, 20, 13, 4) == 0
     d = _lib.AlqpDims(1, 20, 13, 4)
     assert 0 < lib.alqp_lds_bytes(C.byref(d), 0) <= 160 * 1024
     assert lib.alqp_qps_per_wave(C.byref(d), 0) == 1

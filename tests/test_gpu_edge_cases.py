@@ -276,3 +276,31 @@ def test_exit_test_kernel_matches_the_rule():
     be.exit_test(s(float("nan")), ctl, 0)
     be.exit_test(s(float("nan")), ctl, 1)                  # NaN compares false: keeps going (as torch does)
     assert ctl[0].item() == 0.0 and ctl[1].item() == 1.0
+
+
+def test_long_horizon_beyond_team_lds_runs_on_quad_at_small_batch():
+    """T = 400 at (13,4): the team variant's LDS image does not fit; 'auto' must take the quad kernels even
+    at a small batch instead of refusing (alqp_supported is per variant now)."""
+    from deq_mpc_corl_amd import synthetic_problem
+    from deq_mpc_corl_amd.backend import default_backend
+    from oracle import oracle_py as orc
+    be = default_backend()
+    dt = torch.float64
+    B, T, nx, nu = 5, 400, 13, 4
+    assert be.supported(B, T, nx, nu, dt)
+    p = synthetic_problem(B, T, nx, nu, seed=2, dtype=dt, device=DEV)
+    M = T * nx + 2 * T * nu
+    z = p.z0.clone()
+    lam = torch.zeros(B, M, dtype=dt, device=DEV)
+    rho = torch.ones(B, dtype=dt, device=DEV)
+    phi = torch.zeros(B, dtype=dt, device=DEV)
+    info = torch.zeros(B, dtype=torch.int32, device=DEV)
+    st = torch.zeros(B, dtype=torch.uint8, device=DEV)
+    be.solve_lin((B, T, nx, nu), p.Qd, p.q, p.F, p.c, p.x0, p.u_lo, p.u_hi, 0, 0, z, lam, rho, phi, None, info, st,
+                 al_iter=1, max_newton=2, n_ls=20, flags=3)
+    torch.cuda.synchronize()
+    assert be.last_variant == "quad" and int(info.abs().sum()) == 0 and int(st.sum()) == B
+    c = lambda a: a.cpu().numpy()
+    o = orc.solve_lin("f64", c(p.Qd), c(p.q), c(p.F), c(p.c), c(p.x0), c(p.u_lo), c(p.u_hi), c(p.z0), al_iter=1,
+                      max_newton=2, exit_mode="fixed")
+    assert np.abs(c(z) - o["z"]).max() < 1e-8

