@@ -46,3 +46,34 @@ def test_documented_stub_runs_and_matches_the_oracle():
                       al_iter=2, exit_mode="fixed")
     err = np.abs(cpu(ns["z"])[sel] - o["z"]).reshape(64, -1).max(1)
     assert np.median(err) < 1e-5 and (err < 2e-3).mean() >= 0.9     # fp32: near-tie allowance as elsewhere
+
+
+def _ip_stub_source():
+    text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    sec = text[text.index("## 6. Interior-point path"):]
+    return re.search(r"```python\n(.*?)```", sec, re.S).group(1)
+
+
+def test_ip_stub_is_present():
+    src = _ip_stub_source()
+    assert "alqp_ipm_solve_f64" in src and "AlqpIpmParams" in src
+
+
+@pytest.mark.gpu
+def test_documented_ip_stub_runs_and_matches_the_reference_fixture():
+    """The interior-point binding of INTEGRATION.md section 6, executed verbatim on a reference fixture."""
+    from tests import golden_util as gu
+    g = gu.load("ip_cart_f64")
+    dev = "cuda:0"
+    tt = lambda a: torch.as_tensor(np.ascontiguousarray(a)).to(torch.float64).to(dev)
+    ns = dict(B=int(g["B"]), T=int(g["T"]), nx=int(g["nx"]), nu=int(g["nu"]), Cd=tt(g["Cd"]), c=tt(g["c"]), F=tt(g["F"]),
+              f=tt(g["f"]), x0=tt(g["x0"]), u_hi=tt(g["u_hi"]), u_lo=tt(g["u_lo"]))
+    cwd = os.getcwd()
+    os.chdir(ROOT)
+    try:
+        exec(_ip_stub_source(), ns)
+    finally:
+        os.chdir(cwd)
+    torch.cuda.synchronize()
+    err = np.abs(ns["zhat"].cpu().numpy() - g["qp_zhat"][0]).max()
+    assert err < 1e-7 * max(1.0, np.abs(g["qp_zhat"][0]).max()), err
