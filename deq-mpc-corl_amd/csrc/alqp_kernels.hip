@@ -250,6 +250,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     const int T = a.T, M = C::M(T);
 
     Quad<real, NX, NU> qd;
+    __shared__ real w_lds[QCfg<real, NX, NU>::WLDS_WORDS];   // fp64: the W panel (WPanel); one word otherwise
+    qd.wl = w_lds + threadIdx.x;
     qd.q = lane & 3;
     qd.T = T;
     qd.active = active;
@@ -386,6 +388,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     const int b = active ? b_raw : a.B - 1;
     const int T = a.T;
     Quad<real, NX, NU> qd;
+    __shared__ real w_lds[QCfg<real, NX, NU>::WLDS_WORDS];   // fp64: the W panel (WPanel); one word otherwise
+    qd.wl = w_lds + threadIdx.x;
     qd.q = lane & 3;
     qd.T = T;
     qd.active = active;
@@ -426,6 +430,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     const int b = active ? b_raw : a.B - 1;
     const int T = a.T, M = C::M(T);
     Quad<real, NX, NU> qd;
+    __shared__ real w_lds[QCfg<real, NX, NU>::WLDS_WORDS];   // fp64: the W panel (WPanel); one word otherwise
+    qd.wl = w_lds + threadIdx.x;
     qd.q = lane & 3;
     qd.T = T;
     qd.active = active;
@@ -448,7 +454,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     // c_t = xnext_t - F_t z_t into the records (own rows 4s+q)
     const real *gxn = a.xnext + (size_t)b * (T - 1) * NX;
     for (int t = 0; t < T - 1; ++t) {
-        real W[SW][N], zt[N];
+        typename Quad<real, NX, NU>::WT W = qd.wpanel();
+        real zt[N];
         qd.load_F_rows(t, W);
         gload<N>(qd.gz + t * N, zt);
 #pragma unroll

@@ -115,6 +115,38 @@ __device__ inline void gload(const real *p, real (&dst)[LEN]) {
     for (int c = (LEN / 4) * 4; c < LEN; ++c) dst[c] = p[c];
 }
 
+// ---- the nx rows of (-rho) F_t a lane works on during a stage: W[s][k], s < SW, k < N -------------
+// fp32: registers. fp64 (ALQP_W_LDS): LDS, one 64-lane column per word ((s*N + k)*64 + lane: every
+// access is a conflict-free ds_read/write_b64) - the quad kernels use no LDS otherwise, and in fp64
+// these 2*SW*N dwords per lane are what pushed 872 B per lane into scratch (14 GB of HBM traffic per
+// headline launch). 4 x 17 x 64 x 8 B = 34 KB per wavefront, four wavefronts per CU.
+#ifndef ALQP_W_LDS
+#define ALQP_W_LDS 1
+#endif
+template <typename real, int SW, int N, bool IN_LDS>
+struct WPanel {
+    real a[SW][N];
+    __device__ __forceinline__ real (&operator[](int s))[N] { return a[s]; }
+    __device__ __forceinline__ const real (&operator[](int s) const)[N] { return a[s]; }
+};
+template <typename real, int N>
+struct WRowLds {
+    real *p;
+    __device__ __forceinline__ real &operator[](int k) const { return p[k * 64]; }
+};
+template <typename real, int SW, int N>
+struct WPanel<real, SW, N, true> {
+    real *base;  // LDS, already offset by the lane
+    __device__ __forceinline__ WRowLds<real, N> operator[](int s) const { return WRowLds<real, N>{base + s * N * 64}; }
+};
+template <int LEN, typename real>
+__device__ __forceinline__ void gload(const real *p, WRowLds<real, LEN> row) {
+    real tmp[LEN];
+    gload<LEN>(p, tmp);
+#pragma unroll
+    for (int k = 0; k < LEN; ++k) row[k] = tmp[k];
+}
+
 // "no dynamics model": the affine (LinDx) solve reads F and c from the caller's arrays
 struct NoDyn {
     static constexpr int ID = 0;
@@ -144,6 +176,8 @@ struct QCfg {
     // (it would spill 0.7 KB more) and keeps the residual pre-pass + a merit pass
     static constexpr bool PHI0_FWD = sizeof(real) == 4;
     static constexpr bool S_AFTER = sizeof(real) == 8;  // fp64: Schur accumulation after the panel (register pressure)
+    static constexpr bool W_LDS = ALQP_W_LDS && sizeof(real) == 8;       // fp64: the W rows live in LDS (WPanel)
+    static constexpr int WLDS_WORDS = W_LDS ? SW * N * 64 : 1;          // reals of LDS per wavefront
     __host__ __device__ static constexpr int p4(int x) { return (x + 3) & ~3; }
     // The record also carries the stage's slice of every small per-stage array (working copies
     // of z and lam, copies of diag Q, q, c and the bounds): in their own arrays these are 52-68
@@ -178,6 +212,12 @@ struct Quad {
     real *gz, *glam, *rec;
     real rho;
     int info;
+    real *wl;    // fp64: this lane's column of the W panel in LDS (WPanel), else unused
+    using WT = WPanel<real, SW, N, C::W_LDS>;
+    __device__ __forceinline__ WT wpanel() const {
+        if constexpr (C::W_LDS) return WT{wl};
+        else return WT{};
+    }
     real *gFw;   // nonlinear fused solve: this instance's F_t linearisations (inside the workspace; gF points here too)
     real dyn_h;  //   step length of the dynamics model
 
@@ -204,7 +244,7 @@ struct Quad {
     // F_t rows of this lane: row 4s+q (zeros for rows >= NX). Loads are unconditional (row
     // index clamped, result masked) so that all of a stage's loads go out in one batch:
     // a load inside a divergent branch cannot be hoisted and costs its own round trip.
-    __device__ __forceinline__ void load_F_rows(int t, real (&W)[SW][N]) const {
+    __device__ __forceinline__ void load_F_rows(int t, WT &W) const {
         const real *Fg = gF + (size_t)t * NX * N;
 #pragma unroll
         for (int s = 0; s < SW; ++s) {
@@ -254,7 +294,8 @@ struct Quad {
                 if (dyn && have_c) copy_slice<NX>(gc + t * NX, rp + C::oC);
             }
             if (with_residual) {
-                real W[SW][N], zt[N];
+                WT W = wpanel();
+                real zt[N];
                 load_F_rows(dyn ? t : (T > 1 ? T - 2 : 0), W);
                 gload<N>(gz + t * N, zt);
 #pragma unroll
@@ -469,7 +510,7 @@ struct Quad {
         }
         for (int t = 0; t < T; ++t) {
             const bool dyn = t < T - 1;
-            real W[SW][N];
+            WT W = wpanel();
             real Y[N], D[N];
             real v[SW];
             real zs[SY];
@@ -742,7 +783,7 @@ struct Quad {
             real Y[N];
 #pragma unroll
             for (int j = 0; j < N; ++j) Y[j] = qbv(yo[j >> 2], j);
-            real W[SW][N];
+            WT W = wpanel();
             load_F_rows(dyn ? t : (T > 1 ? T - 2 : 0), W);  // same batch as the record loads
             real zz[SY], QQ[SY], qq[SY], lu[SY], ll[SY], bu[SY], bl[SY], rv[SW], lv[SW];
             if constexpr (LS) {
@@ -919,7 +960,7 @@ struct Quad {
                 }
             real Y[N];
             gload<N>(gbar + t * N, Y);
-            real W[SW][N];
+            WT W = wpanel();
             load_F_rows(t > 0 ? t - 1 : 0, W);
 #pragma unroll
             for (int j = 0; j < N; ++j) Y[j] = -Y[j];
