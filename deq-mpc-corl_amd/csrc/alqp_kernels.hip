@@ -234,7 +234,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     using C = QCfg<real, NX, NU>;
     constexpr bool NL = Dyn::ID != 0;
     // fp64 is short of registers already: its line search keeps a pass of its own
-    constexpr bool FUSE_LS = ALQP_FUSE_LS && sizeof(real) == 4 && !NL;
+#ifndef ALQP_FUSE_LS_F64
+#define ALQP_FUSE_LS_F64 1
+#endif
+    constexpr bool FUSE_LS = ALQP_FUSE_LS && (sizeof(real) == 4 || ALQP_FUSE_LS_F64) && !NL;
     constexpr int N = C::N;
     if (a.skip && *a.skip != 0.0) return;  // wave-uniform
     const int lane = threadIdx.x, qi = lane >> 2;

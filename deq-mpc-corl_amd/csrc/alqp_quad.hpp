@@ -174,7 +174,7 @@ struct QCfg {
     static constexpr int LW = lbase(SH);
     // fp32: the starting merit comes out of the first forward sweep; fp64 is short of registers
     // (it would spill 0.7 KB more) and keeps the residual pre-pass + a merit pass
-    static constexpr bool PHI0_FWD = sizeof(real) == 4;
+    static constexpr bool PHI0_FWD = sizeof(real) == 4;   // (fp64, tried again with the W panel in LDS: 520 B of scratch come back)
     static constexpr bool S_AFTER = sizeof(real) == 8;  // fp64: Schur accumulation after the panel (register pressure)
     static constexpr bool W_LDS = ALQP_W_LDS && sizeof(real) == 8;       // fp64: the W rows live in LDS (WPanel)
     static constexpr int WLDS_WORDS = W_LDS ? SW * N * 64 : 1;          // reals of LDS per wavefront
