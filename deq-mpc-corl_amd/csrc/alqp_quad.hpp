@@ -176,7 +176,10 @@ struct QCfg {
     // (it would spill 0.7 KB more) and keeps the residual pre-pass + a merit pass
     static constexpr bool PHI0_FWD = sizeof(real) == 4;   // (fp64, tried again with the W panel in LDS: 520 B of scratch come back)
     static constexpr bool S_AFTER = sizeof(real) == 8;  // fp64: Schur accumulation after the panel (register pressure)
-    static constexpr bool W_LDS = ALQP_W_LDS && sizeof(real) == 8;       // fp64: the W rows live in LDS (WPanel)
+#ifndef ALQP_W_LDS_F32
+#define ALQP_W_LDS_F32 0
+#endif
+    static constexpr bool W_LDS = ALQP_W_LDS && (sizeof(real) == 8 || ALQP_W_LDS_F32);   // the W rows live in LDS (WPanel)
     static constexpr int WLDS_WORDS = W_LDS ? SW * N * 64 : 1;          // reals of LDS per wavefront
     __host__ __device__ static constexpr int p4(int x) { return (x + 3) & ~3; }
     // The record also carries the stage's slice of every small per-stage array (working copies
