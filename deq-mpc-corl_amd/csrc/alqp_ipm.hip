@@ -92,6 +92,16 @@ __device__ inline int wave_or(int v) {
     for (int o = 32; o > 0; o >>= 1) v |= __shfl_xor(v, o, 64);
     return v;
 }
+// value of lane `src` (a compile-time constant after unrolling -> v_readlane_b32, no LDS round trip)
+__device__ inline float lane_bcast(float v, int src) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), src));
+}
+__device__ inline double lane_bcast(double v, int src) {
+    const long long b = __builtin_bit_cast(long long, v);
+    const int lo = __builtin_amdgcn_readlane((int)(b & 0xffffffffll), src);
+    const int hi = __builtin_amdgcn_readlane((int)(b >> 32), src);
+    return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
+}
 __device__ inline float absr(float a) { return __builtin_fabsf(a); }
 __device__ inline double absr(double a) { return __builtin_fabs(a); }
 __device__ inline float sqrtr(float a) { return __builtin_sqrtf(a); }
@@ -237,53 +247,58 @@ struct Ipm {
                 }
             }
             sync();
-            // right-looking Cholesky of sS (lower), NX column steps
-            for (int j = 0; j < NX; ++j) {
-                const real d = sS[j * NX + j];
-                if (!(d > 0) && info == 0) info = m * NX + j + 1;
-                const real il = real(1) / sqrtr(absr(d));   // |d|: modified Cholesky on a non-positive pivot (flagged)
-                sync();
-                if (lane >= j && lane < NX) sS[lane * NX + j] = (lane == j) ? sqrtr(absr(d)) : sS[lane * NX + j] * il;
-                sync();
-                for (int i = lane; i < NN; i += 64) {
-                    const int r = i / NX, q = i % NX;
-                    if (q > j && q <= r) sS[i] -= sS[r * NX + j] * sS[q * NX + j];
+            // Cholesky of S_m and the inverse of its factor WITHOUT LDS round trips: lane r (< NX) holds row r
+            // of the lower triangle in registers; pivots and column entries travel by v_readlane (constant lane
+            // indices after unrolling). 13 column steps cost ~0.5 k instructions instead of 39 barriers.
+            {
+                real row[NX];
+#pragma unroll
+                for (int k = 0; k < NX; ++k) row[k] = (lane < NX && k <= lane) ? sS[(lane < NX ? lane : 0) * NX + k] : real(0);
+#pragma unroll
+                for (int j = 0; j < NX; ++j) {
+                    const real d = lane_bcast(row[j], j);
+                    if (!(d > 0) && info == 0) info = m * NX + j + 1;
+                    const real ad = absr(d);       // |d|: modified Cholesky on a non-positive pivot (flagged)
+                    const real sd = sqrtr(ad);
+                    const real lj = (lane == j) ? sd : row[j] / sd;   // L[r][j], r >= j (lanes above hold unused values)
+                    row[j] = lj;
+#pragma unroll
+                    for (int k = j + 1; k < NX; ++k) row[k] -= lj * lane_bcast(lj, k);   // only entries k <= r are used
                 }
-                sync();
-            }
-            // Linv_m = L^{-1}: lane q builds column q by forward substitution (broadcast reads of L)
-            if (lane < NX) {
+                // Linv = L^{-1}: lane c builds column c by forward substitution; L[i][k] comes from lane i
                 real col[NX];
 #pragma unroll
                 for (int i = 0; i < NX; ++i) {
                     real acc = (i == lane) ? real(1) : real(0);
 #pragma unroll
-                    for (int k = 0; k < i; ++k) acc -= sS[i * NX + k] * col[k];
-                    col[i] = (i >= lane) ? acc / sS[i * NX + i] : real(0);
+                    for (int k = 0; k < i; ++k) acc -= lane_bcast(row[k], i) * col[k];
+                    col[i] = (i >= lane) ? acc / lane_bcast(row[i], i) : real(0);
                 }
+                if (lane < NX) {
 #pragma unroll
-                for (int i = 0; i < NX; ++i) Lm[i * NX + lane] = col[i];
+                    for (int i = 0; i < NX; ++i) Lm[i * NX + lane] = col[i];
+                }
             }
             sync();
         }
     }
 
     // ---- structured solve of the regularised system, rhs b (NK block, x|s|z|y), result into o ----
+    // Phases (a barrier between them): r1 -> right-hand side of S -> 2 sweeps x T stages x 2 -> outputs.
     __device__ void apply(const real *bb, real *o) {
         const real e = a.e;
         const real *zc = w + L.cur + L.oz(), *sc = w + L.cur + L.os();
         const real *Pinv = w + L.pinv, *Dt = w + L.dt;
-        real *wv = w + L.wv, *r1 = w + L.r1;
+        real *r1 = w + L.r1;
         const real *bx = bb, *bs = bb + L.os(), *bz = bb + L.oz(), *by = bb + L.oy();
         real *dx = o, *ds = o + L.os(), *dz = o + L.oz(), *dy = o + L.oy();
-        for (int i = lane; i < L.ni; i += 64) wv[i] = bs[i] / (zc[i] + e) - bz[i];
-        sync();
+        auto wv = [&](int i) { return bs[i] / (zc[i] + e) - bz[i]; };   // bs/(z+eps) - bz, recomputed where needed
         for (int k = lane; k < L.nz; k += 64) {
             const int t = k / N, j = k % N - NX;
             real v = bx[k];
             if (j >= 0) {
                 const int iu = t * NU + j, il = T * NU + iu;
-                v -= Dt[iu] * wv[iu] - Dt[il] * wv[il];
+                v -= Dt[iu] * wv(iu) - Dt[il] * wv(il);
             }
             r1[k] = v;
         }
@@ -304,8 +319,9 @@ struct Ipm {
             sv[i] = v;
         }
         sync();
-        // forward sweep: v_m <- Linv_m (v_m - W_m v_{m-1}); 4 lanes per row
+        // forward sweep: v_m <- Linv_m (v_m - W_m v_{m-1}); 4 lanes per row, the intermediate in sT
         const int row = lane >> 2, part = lane & 3;
+        real *sT = sS;   // the S tile is free outside factor()
         for (int m = 0; m < T; ++m) {
             const real *Lm = Linv + (long)m * NN, *Wm = Wb + (long)m * NN;
             real acc = 0;
@@ -313,15 +329,13 @@ struct Ipm {
                 for (int k = part; k < NX; k += 4) acc += Wm[row * NX + k] * sv[(m - 1) * NX + k];
             acc += __shfl_xor(acc, 1, 64);
             acc += __shfl_xor(acc, 2, 64);
-            sync();
-            if (row < NX && part == 0) sv[m * NX + row] -= acc;
+            if (row < NX && part == 0) sT[row] = sv[m * NX + row] - acc;
             sync();
             real acc2 = 0;
             if (row < NX)
-                for (int k = part; k <= row; k += 4) acc2 += Lm[row * NX + k] * sv[m * NX + k];
+                for (int k = part; k <= row; k += 4) acc2 += Lm[row * NX + k] * sT[k];
             acc2 += __shfl_xor(acc2, 1, 64);
             acc2 += __shfl_xor(acc2, 2, 64);
-            sync();
             if (row < NX && part == 0) sv[m * NX + row] = acc2;
             sync();
         }
@@ -335,28 +349,40 @@ struct Ipm {
             }
             acc += __shfl_xor(acc, 1, 64);
             acc += __shfl_xor(acc, 2, 64);
-            sync();
-            if (row < NX && part == 0) sv[m * NX + row] -= acc;
+            if (row < NX && part == 0) sT[row] = sv[m * NX + row] - acc;
             sync();
             real acc2 = 0;
             if (row < NX)
-                for (int k = row + part; k < NX; k += 4) acc2 += Lm[k * NX + row] * sv[m * NX + k];
+                for (int k = row + part; k < NX; k += 4) acc2 += Lm[k * NX + row] * sT[k];
             acc2 += __shfl_xor(acc2, 1, 64);
             acc2 += __shfl_xor(acc2, 2, 64);
-            sync();
             if (row < NX && part == 0) sv[m * NX + row] = acc2;
             sync();
         }
-        // dy in the reference's row order
-        for (int i = lane; i < L.ne; i += 64) {
-            const int t = i / NX, r = i % NX;
-            dy[i] = (t == T - 1) ? sv[r] : sv[(t + 1) * NX + r];
-        }
-        sync();
-        for (int k = lane; k < L.nz; k += 64) dx[k] = Pinv[k] * (r1[k] - ATy(dy, k));
-        sync();
+        // outputs in one phase: dy (reference row order), dx = Phi^-1 (r1 - A'dy) with dy read from the LDS
+        // sweep result, dz / ds with the control's dx recomputed in place (no barrier in between)
+        auto dyv = [&](int i) { const int t = i / NX, r = i % NX; return (t == T - 1) ? sv[r] : sv[(t + 1) * NX + r]; };
+        auto ATdy = [&](int k) {   // (A' dy)[k] from sv
+            const int t = k / N, j = k % N;
+            real acc = 0;
+            if (t < T - 1) {
+                const real *Fp = Ft(t);
+#pragma unroll
+                for (int r = 0; r < NX; ++r) acc += Fp[r * N + j] * sv[(t + 1) * NX + r];
+            }
+            if (j < NX) {
+                if (t >= 1) acc -= sv[t * NX + j];       // dynamics row t-1 = internal block t
+                else acc += sv[j];                       // initial-state rows = internal block 0
+            }
+            return acc;
+        };
+        for (int i = lane; i < L.ne; i += 64) dy[i] = dyv(i);
+        for (int k = lane; k < L.nz; k += 64) dx[k] = Pinv[k] * (r1[k] - ATdy(k));
         for (int i = lane; i < L.ni; i += 64) {
-            const real zi = Dt[i] * (Gx(dx, i) + wv[i]);
+            const int Tn = T * NU, iu = i < Tn ? i : i - Tn;
+            const int k = (iu / NU) * N + NX + iu % NU;
+            const real du = Pinv[k] * (r1[k] - ATdy(k));
+            const real zi = Dt[i] * ((i < Tn ? du : -du) + wv(i));
             dz[i] = zi;
             ds[i] = (bs[i] - sc[i] * zi) / (zc[i] + e);
         }
