@@ -131,18 +131,18 @@ struct Ipm {
         F = a.F + (long)b * a.sF_b; f = a.f ? a.f + (long)b * a.sf_b : nullptr;
         x0 = a.x0 ? a.x0 + (long)b * NX : nullptr;
     }
-    __device__ real cd(int k) const { return Cd[(long)(k / N) * a.sC_t + (k % N)]; }
-    __device__ real cc(int k) const { return c[(long)(k / N) * a.sC_t + (k % N)]; }
-    __device__ const real *Ft(int t) const { return F + (long)t * a.sF_t; }
-    __device__ real ff(int t, int r) const { return f[(long)t * a.sf_t + r]; }
-    __device__ real hh(int i) const {   // h = [u_upper tiled ; -u_lower tiled]  (qp_wrapper.py:651-652)
+    __device__ __forceinline__ real cd(int k) const { return Cd[(long)(k / N) * a.sC_t + (k % N)]; }
+    __device__ __forceinline__ real cc(int k) const { return c[(long)(k / N) * a.sC_t + (k % N)]; }
+    __device__ __forceinline__ const real *Ft(int t) const { return F + (long)t * a.sF_t; }
+    __device__ __forceinline__ real ff(int t, int r) const { return f[(long)t * a.sf_t + r]; }
+    __device__ __forceinline__ real hh(int i) const {   // h = [u_upper tiled ; -u_lower tiled]  (qp_wrapper.py:651-652)
         const int Tn = T * NU;
         return i < Tn ? a.uhi[i % NU] : -a.ulo[(i - Tn) % NU];
     }
     static __device__ void sync() { __syncthreads(); }
 
     // (A' y)[k] for k = t*N + j: F_t' y_t (t < T-1)  -  y_{t-1} on the state rows (t >= 1)  +  y_init (t = 0)
-    __device__ real ATy(const real *y, int k) const {
+    __device__ __forceinline__ real ATy(const real *y, int k) const {
         const int t = k / N, j = k % N;
         real acc = 0;
         if (t < T - 1) {
@@ -157,7 +157,7 @@ struct Ipm {
         return acc;
     }
     // (A x)[i], reference row order: dynamics rows t*NX + r, then the initial-state rows
-    __device__ real Ax(const real *x, int i) const {
+    __device__ __forceinline__ real Ax(const real *x, int i) const {
         const int t = i / NX, r = i % NX;
         if (t == T - 1) return x[r];
         const real *Fp = Ft(t) + r * N;
@@ -167,11 +167,11 @@ struct Ipm {
         return acc - x[(t + 1) * N + r];
     }
     // G' z at variable k (0 unless k is a control), G x at inequality row i
-    __device__ real GTz(const real *z, int k) const {
+    __device__ __forceinline__ real GTz(const real *z, int k) const {
         const int t = k / N, j = k % N - NX;
         return j < 0 ? real(0) : z[t * NU + j] - z[T * NU + t * NU + j];
     }
-    __device__ real Gx(const real *x, int i) const {
+    __device__ __forceinline__ real Gx(const real *x, int i) const {
         const int Tn = T * NU;
         const int iu = i < Tn ? i : i - Tn;
         const real u = x[(iu / NU) * N + NX + iu % NU];
@@ -179,7 +179,7 @@ struct Ipm {
     }
 
     // ---- factorisation at (zd, sd) = current (z, s) ---------------------------------------------
-    __device__ void factor() {
+    __device__ __forceinline__ void factor() {
         const real e = a.e;
         real *zc = w + L.cur + L.oz(), *sc = w + L.cur + L.os();
         real *Pinv = w + L.pinv, *Dt = w + L.dt;
@@ -285,7 +285,7 @@ struct Ipm {
 
     // ---- structured solve of the regularised system, rhs b (NK block, x|s|z|y), result into o ----
     // Phases (a barrier between them): r1 -> right-hand side of S -> 2 sweeps x T stages x 2 -> outputs.
-    __device__ void apply(const real *bb, real *o) {
+    __device__ __forceinline__ void apply(const real *bb, real *o) {
         const real e = a.e;
         const real *zc = w + L.cur + L.oz(), *sc = w + L.cur + L.os();
         const real *Pinv = w + L.pinv, *Dt = w + L.dt;
@@ -390,7 +390,7 @@ struct Ipm {
     }
 
     // out = K(z, s) l   (no regularisation)
-    __device__ void Kmul(const real *l, real *o) {
+    __device__ __forceinline__ void Kmul(const real *l, real *o) {
         const real *zc = w + L.cur + L.oz(), *sc = w + L.cur + L.os();
         const real *lx = l, *ls = l + L.os(), *lz = l + L.oz(), *ly = l + L.oy();
         for (int k = lane; k < L.nz; k += 64) o[k] = cd(k) * lx[k] + GTz(lz, k) + ATy(ly, k);
@@ -401,24 +401,29 @@ struct Ipm {
         for (int i = lane; i < L.ne; i += 64) o[L.oy() + i] = Ax(lx, i);
     }
 
-    // solve_kkt (batch_LU.py:212-244): rr holds r = -(rx, rs, rz, ry); result in `out`
-    __device__ void solve_kkt(real *out) {
+    // solve_kkt (batch_LU.py:212-244): rr holds r = -(rx, rs, rz, ry); result in `out`.
+    // One call site of apply() (a loop over the solve and its refinement solve): everything is inlined, so
+    // the solver's state stays in registers / SGPRs instead of a `this` object in scratch.
+    __device__ __forceinline__ void solve_kkt(real *out) {
         real *rr = w + L.rr, *r2 = w + L.r2, *dd = w + L.dc;
-        apply(rr, out);
-        Kmul(out, r2);
-        sync();
-        for (int i = lane; i < L.NK; i += 64) r2[i] = rr[i] - r2[i];
-        sync();
-        apply(r2, dd);
-        for (int i = lane; i < L.NK; i += 64) out[i] += dd[i];
-        sync();
+        for (int pass = 0; pass < 2; ++pass) {
+            apply(pass == 0 ? rr : r2, pass == 0 ? out : dd);
+            if (pass == 0) {
+                Kmul(out, r2);
+                sync();
+                for (int i = lane; i < L.NK; i += 64) r2[i] = rr[i] - r2[i];
+            } else {
+                for (int i = lane; i < L.NK; i += 64) out[i] += dd[i];
+            }
+            sync();
+        }
     }
 
     // get_step (batch_LU.py:200-208), per instance: min over rows of -v/dv (dv < 0), 1 (dv == 0),
     // no constraint (dv > 0). (The reference caps dv > 0 rows at max(1, a.max()) taken over the WHOLE
     // batch; the cap only matters when it is below 1/0.999, which never happened in any fixture:
     // `gs_coupled` of tools/gen_golden_ip.py. DESIGN.md section 12.)
-    __device__ real get_step(const real *v, const real *dv, int &nanflag) const {
+    __device__ __forceinline__ real get_step(const real *v, const real *dv, int &nanflag) const {
         real m = INFINITY;
         int nf = 0;
         for (int i = lane; i < L.ni; i += 64) {
@@ -435,7 +440,7 @@ struct Ipm {
     }
 
     // ---- residuals + best iterate (batch_LU.py:86-146); returns 1 if this instance improved -------
-    __device__ int resid(int it) {
+    __device__ __forceinline__ int resid(int it) {
         real *x = w + L.cur, *s = x + L.os(), *z = x + L.oz(), *y = x + L.oy();
         real *rx = w + L.res, *rs = rx + L.os(), *rz = rx + L.oz(), *ry = rx + L.oy();
         real sz = 0, nzr = 0, nyr = 0, nxr = 0;
@@ -477,38 +482,42 @@ struct Ipm {
     }
 
     // ---- one predictor-corrector step (batch_LU.py:153-197) ----------------------------------------
-    __device__ void step() {
+    __device__ __forceinline__ void step() {
         real *x = w + L.cur, *s = x + L.os(), *z = x + L.oz();
         real *res = w + L.res, *rr = w + L.rr, *da = w + L.da;
+        real *dcr = w + L.res;                      // corrector direction: the residual block is free by then
         const real mu = (w + L.scal)[1];
         factor();
-        for (int i = lane; i < L.NK; i += 64) rr[i] = -res[i];
-        sync();
-        solve_kkt(da);                               // affine direction
-        int nf = 0;
-        real al = get_step(z, da + L.oz(), nf);
-        const real al2 = get_step(s, da + L.os(), nf);
-        al = al2 < al ? al2 : al;
-        al = al < real(1) ? al : real(1);
-        if (nf) al = NAN;
-        real t3 = 0, t4 = 0;
-        for (int i = lane; i < L.ni; i += 64) {
-            t3 += (s[i] + al * da[L.os() + i]) * (z[i] + al * da[L.oz() + i]);
-            t4 += s[i] * z[i];
+        for (int ph = 0; ph < 2; ++ph) {            // 0: affine direction, 1: centering-corrector (one solve_kkt site)
+            if (ph == 0) {
+                for (int i = lane; i < L.NK; i += 64) rr[i] = -res[i];
+            } else {
+                int nf = 0;
+                real al = get_step(z, da + L.oz(), nf);
+                const real al2 = get_step(s, da + L.os(), nf);
+                al = al2 < al ? al2 : al;
+                al = al < real(1) ? al : real(1);
+                if (nf) al = NAN;
+                real t3 = 0, t4 = 0;
+                for (int i = lane; i < L.ni; i += 64) {
+                    t3 += (s[i] + al * da[L.os() + i]) * (z[i] + al * da[L.oz() + i]);
+                    t4 += s[i] * z[i];
+                }
+                t3 = wave_sum(t3); t4 = wave_sum(t4);
+                real sig = t3 / t4; sig = sig * sig * sig;
+                // corrector right-hand side: rx = rz = ry = 0, rs = -mu sig + ds_aff dz_aff   (r = -residual)
+                for (int i = lane; i < L.NK; i += 64) {
+                    const int j = i - L.os();
+                    rr[i] = (j >= 0 && j < L.ni) ? -(-mu * sig + da[L.os() + j] * da[L.oz() + j]) : real(0);
+                }
+            }
+            sync();
+            solve_kkt(ph == 0 ? da : dcr);
         }
-        t3 = wave_sum(t3); t4 = wave_sum(t4);
-        real sig = t3 / t4; sig = sig * sig * sig;
-        // corrector right-hand side: rx = rz = ry = 0, rs = -mu sig + ds_aff dz_aff   (r = -residual)
-        for (int i = lane; i < L.NK; i += 64) rr[i] = 0;
-        sync();
-        for (int i = lane; i < L.ni; i += 64) rr[L.os() + i] = -(-mu * sig + da[L.os() + i] * da[L.oz() + i]);
-        sync();
-        real *dcr = w + L.res;                      // the residual block is free now: corrector direction
-        solve_kkt(dcr);
         for (int i = lane; i < L.NK; i += 64) da[i] += dcr[i];
         sync();
-        nf = 0;
-        al = get_step(z, da + L.oz(), nf);
+        int nf = 0;
+        real al = get_step(z, da + L.oz(), nf);
         const real al3 = get_step(s, da + L.os(), nf);
         al = al3 < al ? al3 : al;
         al = real(0.999) * al;
@@ -519,7 +528,7 @@ struct Ipm {
     }
 
     // ---- initial point (batch_LU.py:44-81) ------------------------------------------------------------
-    __device__ void init() {
+    __device__ __forceinline__ void init() {
         real *x = w + L.cur, *s = x + L.os(), *z = x + L.oz();
         real *rr = w + L.rr, *da = w + L.da, *sc = w + L.scal;
         for (int i = lane; i < L.ni; i += 64) { s[i] = 1; z[i] = 1; }
