@@ -427,3 +427,53 @@ def test_backward_quad_workspace_equals_team_factor(exit_mode):
     sq = float(grads["team"][0].abs().max())
     assert float((grads["quad"][0] - grads["team"][0]).abs().max()) < 1e-6 * sq
     assert float((grads["quad"][1] - grads["team"][1]).abs().max()) < 1e-6 * float(grads["team"][1].abs().max())
+
+
+@pytest.mark.parametrize("cfg", ["pendulum T=5 B=4096 f32 (BASELINE config 2)", "(8,2) T=10 B=8192 f32 (config 3)",
+                                 "(13,4) T=50 B=65536 f32 (config 5, whole on one GPU)"])
+def test_baseline_configs_full_size_properties(cfg):
+    """BASELINE.json's other configurations at FULL size through the default ('auto' -> quad) path, checked by
+    size-independent properties (no oracle run of that size): every instance ok, bit-exact invariance
+    under a permutation of the batch, the AL solve reduces the constraint violation, idempotent re-run
+    (same inputs -> same bits), plus a 32-instance sample against the oracle."""
+    from deq_mpc_corl_amd import synthetic_problem
+    from deq_mpc_corl_amd.backend import default_backend
+    be = default_backend()
+    B, T, nx, nu = {"pend": (4096, 5, 2, 1), "(8,2": (8192, 10, 8, 2), "(13,": (65536, 50, 13, 4)}[cfg[:4]]
+    dt = torch.float32
+    p = synthetic_problem(B, T, nx, nu, seed=0, dtype=dt, device=DEV)
+    M = T * nx + 2 * T * nu
+
+    def solve(perm=None):
+        sel = (lambda a: a) if perm is None else (lambda a: a[perm].contiguous())
+        z = sel(p.z0).clone()
+        lam = torch.zeros(B, M, dtype=dt, device=DEV)
+        rho = torch.ones(B, dtype=dt, device=DEV)
+        phi = torch.zeros(B, dtype=dt, device=DEV)
+        rn2 = torch.zeros(B, dtype=dt, device=DEV)
+        info = torch.zeros(B, dtype=torch.int32, device=DEV)
+        st = torch.zeros(B, dtype=torch.uint8, device=DEV)
+        be.solve_lin((B, T, nx, nu), sel(p.Qd), sel(p.q), sel(p.F), sel(p.c), sel(p.x0), p.u_lo, p.u_hi,
+                     0, 0, z, lam, rho, phi, rn2, info, st, al_iter=2, max_newton=4, n_ls=20, flags=3)
+        torch.cuda.synchronize()
+        return z, lam, rn2, info, st
+
+    z, lam, rn2, info, st = solve()
+    assert be.last_variant == "quad"
+    assert int(info.abs().sum()) == 0 and int(st.sum()) == B
+    z1, lam1, _, _, _ = solve()
+    assert torch.equal(z1, z) and torch.equal(lam1, lam)                      # idempotent
+    perm = torch.randperm(B, device=DEV, generator=torch.Generator(device=DEV).manual_seed(1))
+    z2, lam2, _, _, _ = solve(perm)
+    assert torch.equal(z2, z[perm]) and torch.equal(lam2, lam[perm])          # position in the batch does not matter
+    xn0 = torch.einsum("btij,btj->bti", p.F, p.z0[:, :-1]) + p.c
+    r0 = ((p.z0[:, 1:, :nx] - xn0) ** 2).sum((1, 2)) + ((p.z0[:, 0, :nx] - p.x0) ** 2).sum(1)
+    assert float(rn2.mean()) < 0.35 * float(r0.mean())
+    idx = np.arange(0, B, B // 32)
+    c = lambda a: a[idx].cpu().numpy()
+    o = orc.solve_lin("f32", c(p.Qd), c(p.q), c(p.F), c(p.c), c(p.x0), p.u_lo.cpu().numpy(),
+                      p.u_hi.cpu().numpy(), c(p.z0), al_iter=2, exit_mode="fixed", trace_steps=8)
+    ok = ~near_tie_instances(o, "f32")
+    prob = dict(Qd=c(p.Qd), q=c(p.q), F=c(p.F), c=c(p.c), x0=c(p.x0), u_lo=p.u_lo.cpu().numpy(), u_hi=p.u_hi.cpu().numpy())
+    check_excluded("f32", ~ok, c(z), c(lam), np.full(len(idx), 100.0, np.float32), o, prob, max_frac=0.27, label=cfg)
+    assert np.abs(c(z) - o["z"])[ok].max() < 5e-3
