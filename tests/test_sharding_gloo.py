@@ -96,3 +96,58 @@ def test_shard_range_covers_batch():
             assert rs[0][0] == 0 and rs[-1][1] == B
             assert all(rs[i][1] == rs[i + 1][0] for i in range(w - 1))
             assert max(h - l for l, h in rs) - min(h - l for l, h in rs) <= 1
+
+
+def _stream_worker(rank, world, port, name, out_dir):
+    """reinitialize -> call -> warm_start_initialize -> stream calls on this rank's slab (tests/test_stream_golden.py
+    does the same un-sharded)."""
+    from types import SimpleNamespace
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    from deq_mpc_corl_amd import PendulumDynamics, QuadCost
+    from deq_mpc_corl_amd.sharding import gather_batch, make_sharded_mpc, shard
+    from tests.oracle_backend import OracleBackend
+    g = gu.load(name)
+    dt = torch.float64
+    B, T, nx, nu = g["B"], g["T"], g["nx"], g["nu"]
+    t = lambda a, d=dt: shard(torch.as_tensor(np.ascontiguousarray(a)).to(d), rank, world)
+    mpc = make_sharded_mpc(nx, nu, T, torch.as_tensor(g["u_lo"]).to(dt), torch.as_tensor(g["u_hi"]).to(dt),
+                           B, rank, world, dtype=dt, exit_mode="reference", backend=OracleBackend())
+    x0, Qd = t(g["x0"]), t(g["Qd"])
+    Bl = x0.shape[0]
+    zeros = torch.zeros(Bl, T, dtype=dt)
+    dyn = PendulumDynamics()
+    mpc.reinitialize(x0, None)
+    mpc.al_iter = int(g["al_iter_first"])
+    z0 = t(g["z0"])
+    mpc(x0, QuadCost(torch.diag_embed(Qd), t(g["q0"]), zeros), dyn, dyn.jac, x_init=z0[..., :nx].clone(), u_init=z0[..., nx:].clone())
+    mpc.warm_start_initialize(t(g["x_warm"], torch.float32), t(g["u_warm"], torch.float32),
+                              SimpleNamespace(rho_init_max=float(g["rho_init_max"])))
+    mpc.linearize_once = bool(int(g["linearize_once"]))
+    n_al, xs, us, sts = [], [], [], []
+    for ci in range(int(g["stream_calls"])):
+        mpc.al_iter = int(g["al_iter_stream"])
+        q = torch.as_tensor(np.ascontiguousarray(g["q"][ci])).to(dt)
+        x, u, st = mpc(x0, QuadCost(torch.diag_embed(Qd), shard(q, rank, world), zeros), dyn, dyn.jac)
+        n_al.append(len(mpc.last_newton_per_al))
+        xs.append(gather_batch(x, B).numpy()); us.append(gather_batch(u, B).numpy()); sts.append(int(st))
+    if rank == 0:
+        np.savez(os.path.join(out_dir, "stream.npz"), x=np.stack(xs), u=np.stack(us), n_al=np.array(n_al), status=np.array(sts))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_stream_linearize_once_breaks_in_the_same_iteration_on_every_rank(tmp_path):
+    """The stream loop's break test is a BATCH mean (AL_mpc.py:406-408) and rho.max() (:412): with the batch
+    sharded both are all-reduced (MPC._global_mean / _global_max), so every rank leaves the loop in the
+    iteration the un-sharded reference did; a rank-local mean would leave the ranks with different
+    iteration counts and the next all-reduce would hang."""
+    name = "pend_stream_lin_f64"
+    g = gu.load(name)
+    mp.spawn(_stream_worker, args=(2, _free_port(), name, str(tmp_path)), nprocs=2, join=True)
+    out = np.load(tmp_path / "stream.npz")
+    assert out["n_al"].tolist() == g["n_al"].tolist()
+    assert out["status"].tolist() == g["status"].tolist()
+    assert np.abs(out["x"] - g["x"]).max() < 2e-5 and np.abs(out["u"] - g["u"]).max() < 2e-5
