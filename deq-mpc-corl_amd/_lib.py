@@ -95,6 +95,7 @@ _PLAIN = {
     "alqp_exit_test": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_void_p]),
     "alqp_workspace_bytes_nonlin": (C.c_size_t, [C.POINTER(AlqpDims), C.c_int]),
     "alqp_ipm_workspace_bytes": (C.c_size_t, [C.POINTER(AlqpDims), C.c_int]),
+    "alqp_ipm_set_factor_placement": (C.c_int, [C.c_int]),
 }
 
 EXPORTED_SYMBOLS = sorted([f"{n}_{s}" for n in _SIGS for s in ("f32", "f64")] + list(_PLAIN))

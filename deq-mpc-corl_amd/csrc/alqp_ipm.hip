@@ -102,6 +102,24 @@ __device__ inline double lane_bcast(double v, int src) {
     const int hi = __builtin_amdgcn_readlane((int)(b >> 32), src);
     return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
 }
+// all-reduce over the 4 lanes of a quad by DPP quad_perm (VALU, no LDS crossbar round trip like __shfl_xor)
+template <int CTRL>
+__device__ inline float quad_perm(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+template <int CTRL>
+__device__ inline double quad_perm(double v) {
+    const long long b = __builtin_bit_cast(long long, v);
+    const int lo = __builtin_amdgcn_mov_dpp((int)(b & 0xffffffffll), CTRL, 0xF, 0xF, true);
+    const int hi = __builtin_amdgcn_mov_dpp((int)(b >> 32), CTRL, 0xF, 0xF, true);
+    return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
+}
+template <typename real>
+__device__ inline real quad_sum(real v) {
+    v += quad_perm<0xB1>(v);  // quad_perm [1,0,3,2]
+    v += quad_perm<0x4E>(v);  // quad_perm [2,3,0,1]
+    return v;
+}
 __device__ inline float absr(float a) { return __builtin_fabsf(a); }
 __device__ inline double absr(double a) { return __builtin_fabs(a); }
 __device__ inline float sqrtr(float a) { return __builtin_sqrtf(a); }
@@ -287,12 +305,16 @@ struct Ipm {
     // Phases (a barrier between them): r1 -> right-hand side of S -> 2 sweeps x T stages x 2 -> outputs.
     __device__ __forceinline__ void apply(const real *bb, real *o) {
         const real e = a.e;
-        const real *zc = w + L.cur + L.oz(), *sc = w + L.cur + L.os();
-        const real *Pinv = w + L.pinv, *Dt = w + L.dt;
-        real *r1 = w + L.r1;
-        const real *bx = bb, *bs = bb + L.os(), *bz = bb + L.oz(), *by = bb + L.oy();
-        real *dx = o, *ds = o + L.os(), *dz = o + L.oz(), *dy = o + L.oy();
+        // the slabs do not overlap: telling the compiler lets it keep several lanes-strided iterations of the
+        // element-wise loops in flight instead of one global round trip per iteration
+        const real *__restrict__ zc = w + L.cur + L.oz(), *__restrict__ sc = w + L.cur + L.os();
+        const real *__restrict__ Pinv = w + L.pinv, *__restrict__ Dt = w + L.dt;
+        real *__restrict__ r1 = w + L.r1;
+        const real *__restrict__ bx = bb, *__restrict__ bs = bb + L.os(), *__restrict__ bz = bb + L.oz(),
+                   *__restrict__ by = bb + L.oy();
+        real *__restrict__ dx = o, *__restrict__ ds = o + L.os(), *__restrict__ dz = o + L.oz(), *__restrict__ dy = o + L.oy();
         auto wv = [&](int i) { return bs[i] / (zc[i] + e) - bz[i]; };   // bs/(z+eps) - bz, recomputed where needed
+#pragma unroll 4
         for (int k = lane; k < L.nz; k += 64) {
             const int t = k / N, j = k % N - NX;
             real v = bx[k];
@@ -304,6 +326,7 @@ struct Ipm {
         }
         sync();
         // rhs of S in internal block order (block 0 = initial-state rows, block t+1 = dynamics t) -> sv
+#pragma unroll 4
         for (int i = lane; i < L.ne; i += 64) {
             const int m = i / NX, r = i % NX;
             real v;
@@ -327,15 +350,13 @@ struct Ipm {
             real acc = 0;
             if (m > 0 && row < NX)
                 for (int k = part; k < NX; k += 4) acc += Wm[row * NX + k] * sv[(m - 1) * NX + k];
-            acc += __shfl_xor(acc, 1, 64);
-            acc += __shfl_xor(acc, 2, 64);
+            acc = quad_sum(acc);
             if (row < NX && part == 0) sT[row] = sv[m * NX + row] - acc;
             sync();
             real acc2 = 0;
             if (row < NX)
                 for (int k = part; k <= row; k += 4) acc2 += Lm[row * NX + k] * sT[k];
-            acc2 += __shfl_xor(acc2, 1, 64);
-            acc2 += __shfl_xor(acc2, 2, 64);
+            acc2 = quad_sum(acc2);
             if (row < NX && part == 0) sv[m * NX + row] = acc2;
             sync();
         }
@@ -347,15 +368,13 @@ struct Ipm {
                 const real *Wn = Wb + (long)(m + 1) * NN;
                 for (int k = part; k < NX; k += 4) acc += Wn[k * NX + row] * sv[(m + 1) * NX + k];
             }
-            acc += __shfl_xor(acc, 1, 64);
-            acc += __shfl_xor(acc, 2, 64);
+            acc = quad_sum(acc);
             if (row < NX && part == 0) sT[row] = sv[m * NX + row] - acc;
             sync();
             real acc2 = 0;
             if (row < NX)
                 for (int k = row + part; k < NX; k += 4) acc2 += Lm[k * NX + row] * sT[k];
-            acc2 += __shfl_xor(acc2, 1, 64);
-            acc2 += __shfl_xor(acc2, 2, 64);
+            acc2 = quad_sum(acc2);
             if (row < NX && part == 0) sv[m * NX + row] = acc2;
             sync();
         }
@@ -376,8 +395,11 @@ struct Ipm {
             }
             return acc;
         };
+#pragma unroll 4
         for (int i = lane; i < L.ne; i += 64) dy[i] = dyv(i);
+#pragma unroll 4
         for (int k = lane; k < L.nz; k += 64) dx[k] = Pinv[k] * (r1[k] - ATdy(k));
+#pragma unroll 4
         for (int i = lane; i < L.ni; i += 64) {
             const int Tn = T * NU, iu = i < Tn ? i : i - Tn;
             const int k = (iu / NU) * N + NX + iu % NU;
@@ -391,28 +413,34 @@ struct Ipm {
 
     // out = K(z, s) l   (no regularisation)
     __device__ __forceinline__ void Kmul(const real *l, real *o) {
-        const real *zc = w + L.cur + L.oz(), *sc = w + L.cur + L.os();
-        const real *lx = l, *ls = l + L.os(), *lz = l + L.oz(), *ly = l + L.oy();
-        for (int k = lane; k < L.nz; k += 64) o[k] = cd(k) * lx[k] + GTz(lz, k) + ATy(ly, k);
+        const real *__restrict__ zc = w + L.cur + L.oz(), *__restrict__ sc = w + L.cur + L.os();
+        const real *__restrict__ lx = l, *__restrict__ ls = l + L.os(), *__restrict__ lz = l + L.oz(), *__restrict__ ly = l + L.oy();
+        real *__restrict__ ox = o, *__restrict__ oS = o + L.os(), *__restrict__ oZ = o + L.oz(), *__restrict__ oY = o + L.oy();
+#pragma unroll 4
+        for (int k = lane; k < L.nz; k += 64) ox[k] = cd(k) * lx[k] + GTz(lz, k) + ATy(ly, k);
+#pragma unroll 4
         for (int i = lane; i < L.ni; i += 64) {
-            o[L.os() + i] = zc[i] * ls[i] + sc[i] * lz[i];
-            o[L.oz() + i] = Gx(lx, i) + ls[i];
+            oS[i] = zc[i] * ls[i] + sc[i] * lz[i];
+            oZ[i] = Gx(lx, i) + ls[i];
         }
-        for (int i = lane; i < L.ne; i += 64) o[L.oy() + i] = Ax(lx, i);
+#pragma unroll 4
+        for (int i = lane; i < L.ne; i += 64) oY[i] = Ax(lx, i);
     }
 
     // solve_kkt (batch_LU.py:212-244): rr holds r = -(rx, rs, rz, ry); result in `out`.
     // One call site of apply() (a loop over the solve and its refinement solve): everything is inlined, so
     // the solver's state stays in registers / SGPRs instead of a `this` object in scratch.
     __device__ __forceinline__ void solve_kkt(real *out) {
-        real *rr = w + L.rr, *r2 = w + L.r2, *dd = w + L.dc;
+        real *__restrict__ rr = w + L.rr, *__restrict__ r2 = w + L.r2, *__restrict__ dd = w + L.dc;
         for (int pass = 0; pass < 2; ++pass) {
             apply(pass == 0 ? rr : r2, pass == 0 ? out : dd);
             if (pass == 0) {
                 Kmul(out, r2);
                 sync();
+#pragma unroll 4
                 for (int i = lane; i < L.NK; i += 64) r2[i] = rr[i] - r2[i];
             } else {
+#pragma unroll 4
                 for (int i = lane; i < L.NK; i += 64) out[i] += dd[i];
             }
             sync();
@@ -444,10 +472,12 @@ struct Ipm {
         real *x = w + L.cur, *s = x + L.os(), *z = x + L.oz(), *y = x + L.oy();
         real *rx = w + L.res, *rs = rx + L.os(), *rz = rx + L.oz(), *ry = rx + L.oy();
         real sz = 0, nzr = 0, nyr = 0, nxr = 0;
+#pragma unroll 4
         for (int k = lane; k < L.nz; k += 64) {
             const real v = cd(k) * x[k] + cc(k) + GTz(z, k) + ATy(y, k);
             rx[k] = v; nxr += v * v;
         }
+#pragma unroll 4
         for (int i = lane; i < L.ni; i += 64) {
             const real p = s[i] * z[i];
             rs[i] = p; sz += p;
@@ -473,6 +503,7 @@ struct Ipm {
         sync();
         if (better) {
             real *bst = w + L.best;
+#pragma unroll 4
             for (int i = lane; i < L.NK; i += 64) bst[i] = x[i];
             if (lane == 0) { sc[0] = rsd; sc[2] = 1; sc[3] = real(it); }
         }
@@ -514,6 +545,7 @@ struct Ipm {
             sync();
             solve_kkt(ph == 0 ? da : dcr);
         }
+#pragma unroll 4
         for (int i = lane; i < L.NK; i += 64) da[i] += dcr[i];
         sync();
         int nf = 0;
@@ -523,6 +555,7 @@ struct Ipm {
         al = real(0.999) * al;
         al = al < real(1) ? al : real(1);
         if (nf) al = NAN;
+#pragma unroll 4
         for (int i = lane; i < L.NK; i += 64) x[i] += al * da[i];
         sync();
     }
@@ -623,11 +656,31 @@ __global__ __launch_bounds__(64) void k_ipm_backward(const IpmArgs<real> a, cons
 
 constexpr size_t kLdsLimit = 64 * 1024;   // per-workgroup LDS the launch may ask for
 
+// Where the Schur factor lives. LDS: lowest latency per QP, but 27 / 54 KB (fp32 / fp64 at (20,13,4)) leave 5 / 2
+// wavefronts per CU. Workspace (L2 / Infinity Cache): every sweep stage waits on a global round trip, but the
+// launch then runs 8 wavefronts per CU (register-limited) and hides it - faster as soon as the batch fills the
+// chip that way (measured). ALQP_IPM_FAC: 0 auto, 1 always LDS, 2 always workspace.
+#ifndef ALQP_IPM_FAC
+#define ALQP_IPM_FAC 0
+#endif
+static int g_ipm_fac_mode = ALQP_IPM_FAC;
 template <typename real, int NX, int NU>
-static bool fac_in_lds(int T) { return lds_words<real, NX, NU>(T, true) * sizeof(real) <= kLdsLimit; }
+static bool fac_fits_lds(int T) { return lds_words<real, NX, NU>(T, true) * sizeof(real) <= kLdsLimit; }
+template <typename real, int NX, int NU>
+static bool fac_in_lds(int T, int B) {
+    if (!fac_fits_lds<real, NX, NU>(T) || g_ipm_fac_mode == 2) return false;
+    if (g_ipm_fac_mode == 1) return true;
+    // auto: LDS while it still allows >= 4 wavefronts per CU (160 KB), or when the batch is too small to
+    // fill the chip with enough wavefronts to hide the workspace latency. Measured at (20,13,4), B = 8192:
+    // fp64 (2 per CU in LDS) 65 k -> 106 k QP/s in the workspace; fp32 (5 per CU in LDS) 160 k vs 140 k; B = 512:
+    // LDS 65 k / 81 k vs workspace 19 k / 58 k.
+    const long per_cu = (160L * 1024) / (lds_words<real, NX, NU>(T, true) * (long)sizeof(real));
+    return B < 2048 || per_cu >= 4;
+}
 
+// (the workspace always reserves the factor region, so that its size does not depend on the placement)
 template <typename real, int NX, int NU>
-static size_t ws_words_for(int T) { return Lay<real, NX, NU>(T, !fac_in_lds<real, NX, NU>(T)).total; }
+static size_t ws_words_for(int T) { return Lay<real, NX, NU>(T, true).total; }
 
 template <typename real>
 static size_t ws_bytes(int nx, int nu, int B, int T) {
@@ -640,7 +693,7 @@ static size_t ws_bytes(int nx, int nu, int B, int T) {
 
 template <typename real, int NX, int NU>
 static int launch(IpmArgs<real> a, const real *lams, const real *slacks, bool backward, hipStream_t stream) {
-    const bool fl = fac_in_lds<real, NX, NU>(a.T);
+    const bool fl = fac_in_lds<real, NX, NU>(a.T, a.B);
     a.ws_words = (long)ws_words_for<real, NX, NU>(a.T);
     const size_t lds = lds_words<real, NX, NU>(a.T, fl) * sizeof(real);
     if (lds > kLdsLimit) return ALQP_E_UNSUPPORTED;
@@ -717,6 +770,12 @@ static int backward_impl(const AlqpDims *d, const void *Cd, const void *F, long 
 }  // namespace alqp_ipm
 
 extern "C" {
+
+int alqp_ipm_set_factor_placement(int mode) {
+    if (mode < 0 || mode > 2) return ALQP_E_BADARG;
+    alqp_ipm::g_ipm_fac_mode = mode;
+    return 0;
+}
 
 size_t alqp_ipm_workspace_bytes(const AlqpDims *dims, int is_f64) {
     if (!alqp_ipm::dims_ok(dims)) return 0;

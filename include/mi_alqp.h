@@ -371,6 +371,11 @@ typedef struct AlqpIpmParams {
 } AlqpIpmParams;
 
 size_t alqp_ipm_workspace_bytes(const AlqpDims *dims, int is_f64);
+/* Tuning knob (process-wide): where the Schur factor of alqp_ipm_solve / _backward lives. 0 = auto (LDS while it
+ * leaves >= 4 wavefronts per CU or the batch is below 2048; else the workspace, where more wavefronts per CU
+ * hide its latency), 1 = always LDS when it fits,
+ * 2 = always the workspace. Results are identical. */
+int alqp_ipm_set_factor_placement(int mode);
 int alqp_ipm_solve_f32(const AlqpDims *dims, const AlqpIpmParams *prm, const void *Cd, const void *c,
                        const void *F, const void *f, const void *x0, const void *u_hi, const void *u_lo,
                        long sC_t, long sC_b, long sF_t, long sF_b, long sf_t, long sf_b, void *workspace,
