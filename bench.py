@@ -256,8 +256,10 @@ def bench_extras(args, torch, be, _lib, dev, dims, p, run_solve, barrier):
         d = torch.empty(B, T, n, dtype=dt, device=dev)
         info = torch.zeros(B, dtype=torch.int32, device=dev)
         k = max(5, args.steps // 2)
+        # the drop-in class takes the quad kernels (16 instances per wavefront) from B = 4096, the team kernels below
+        wsq = be._workspace(dims, p.z0)[0] if B >= be.QUAD_MIN_BATCH else None
         el, kms = timed(torch, lambda i: be.newton_step(dims, p.z0, xn, p.F, p.x0, lam, rho, p.Qd, p.q, p.u_lo, p.u_hi,
-                                                         0, 0, d, info=info), k, 2, barrier)
+                                                         0, 0, d, info=info, workspace=wsq), k, 2, barrier)
         words = 3 * T * n + (T - 1) * nx * n + T * nx + M + 1 + T * n
         sz = p.z0.element_size()
         out["newton_step"] = {"value": B * k / el, "unit": "Newton steps/s", "kernel_ms": kms,
