@@ -13,7 +13,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libmi_alqp.so")
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 
 class AlqpDims(C.Structure):
@@ -32,7 +32,7 @@ class AlqpTrace(C.Structure):
 
 
 class AlqpObstacles(C.Structure):
-    _fields_ = [("pos", C.c_void_p), ("radius", C.c_double), ("nobs", C.c_int)]
+    _fields_ = [("pos", C.c_void_p), ("radius", C.c_double), ("nobs", C.c_int), ("state_estimator", C.c_int)]
 
 
 class AlqpIpmParams(C.Structure):

@@ -220,11 +220,13 @@ class HipBackend:
     @staticmethod
     def _obs_struct(obs, dims, dt):
         """obs = (pos [B,T,nobs,3] tensor, radius float) -> AlqpObstacles (Obstacle_MPC rows)."""
+        if isinstance(obs, str) and obs == "state_estimator":     # that variant's row set and gradient, no obstacle rows
+            return _lib.AlqpObstacles(None, 0.0, 0, 1)
         pos, radius = obs
         B, T = dims[0], dims[1]
         if pos.dim() != 4 or pos.shape[0] != B or pos.shape[1] != T or pos.shape[3] != 3:
             raise ValueError(f"mi_alqp: obstacle centres must be [B,T,nobs,3], got {tuple(pos.shape)}")
-        return _lib.AlqpObstacles(_ptr(pos, "obstacle centres", dt).value, float(radius), int(pos.shape[2]))
+        return _lib.AlqpObstacles(_ptr(pos, "obstacle centres", dt).value, float(radius), int(pos.shape[2]), 0)
 
     def newton_step(self, dims, z, xnext, F, x0, lam, rho, Qd, q, ulo, uhi, sb_u, st_u, d_out,
                     g_out=None, factor=None, info=None, obs=None, workspace=None):

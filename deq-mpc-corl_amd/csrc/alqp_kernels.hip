@@ -55,6 +55,7 @@ struct StepArgs {
     const real *obs;   // nullable [B][T][nobs][3]: obstacle centres (Obstacle_MPC)
     int nobs;
     real obs_r2;
+    int no_init;       // state-estimator row set (AlqpObstacles.state_estimator)
 };
 
 template <typename real>
@@ -503,6 +504,7 @@ __global__ __launch_bounds__(64) void k_newton_step(StepArgs<real> a) {
     Team<real, NX, NU> tm;
     tm.init(smem + (size_t)team * C::team_words(T) + opaque_zero(), li, team * G, T, b);
     if (a.nobs > 0) { tm.gobs = a.obs + (size_t)b * T * a.nobs * 3; tm.nobs = a.nobs; tm.obs_r2 = a.obs_r2; }
+    tm.no_init = a.no_init != 0;
     tm.gQd = a.Qd + (size_t)b * T * N;
     tm.gq = a.q + (size_t)b * T * N;
     tm.gF = a.F + (size_t)b * (T - 1) * NX * N;
@@ -591,6 +593,7 @@ struct AuxArgs {
     const real *obs;
     int nobs;
     real obs_r2;
+    int no_init;   // state-estimator row set: the initial-state rows (row block T-1) do not exist
 };
 
 // c_k = r^2 - |x_t[0:3] - o_k|^2 for obstacle row e = t*nobs + k of instance b (al_utils.py:313-323)
@@ -634,7 +637,8 @@ __global__ __launch_bounds__(64) void k_merit(AuxArgs<real> a) {
         acc += lam[neq + (e / a.nobs) * nit + 2 * nu + e % a.nobs] * ck;
         sq += cp * cp;
     }
-    for (int e = lane; e < neq; e += 64) {
+    const int neq_rows = a.no_init ? neq - nx : neq;
+    for (int e = lane; e < neq_rows; e += 64) {
         int t = e / nx, i = e - t * nx;
         real r = (t < T - 1) ? z[(t + 1) * n + i] - xn[t * nx + i] : z[i] - a.x0[(size_t)b * nx + i];
         acc += lam[e] * r;
@@ -692,7 +696,7 @@ __global__ __launch_bounds__(64) void k_merit_pick(AuxArgs<real> a) {
         }
     }
     // equality rows: r = x_{t+1}(candidate) - xnext_k, init rows x_0 - x0
-    for (int e = lane; e < neq; e += 64) {
+    for (int e = lane; e < (a.no_init ? neq - nx : neq); e += 64) {
         const int t = e / nx, i = e - t * nx;
         const real le = lam[e];
         const int zi = (t < T - 1) ? (t + 1) * n + i : i;
@@ -789,7 +793,7 @@ __global__ __launch_bounds__(64) void k_dual(AuxArgs<real> a) {
     real *lam = a.lam_io + (size_t)b * (neq + T * nit);
     const real *ulo = a.ulo + (size_t)b * a.sb_u, *uhi = a.uhi + (size_t)b * a.sb_u;
     const real rho = a.rho_io[b];
-    for (int e = lane; e < neq; e += 64) {
+    for (int e = lane; e < (a.no_init ? neq - nx : neq); e += 64) {
         int t = e / nx, i = e - t * nx;
         real r = (t < T - 1) ? z[(t + 1) * n + i] - xn[t * nx + i] : z[i] - a.x0[(size_t)b * nx + i];
         lam[e] += rho * r;
@@ -1081,13 +1085,14 @@ int newton_step_impl(const AlqpDims *dims, const void *z, const void *xnext, con
     if (obs && (obs->nobs < 0 || (obs->nobs > 0 && (!obs->pos || dims->nx < 3)))) return ALQP_E_BADARG;
     StepArgs<real> a = {};
     if (obs && obs->nobs > 0) { a.obs = (const real *)obs->pos; a.nobs = obs->nobs; a.obs_r2 = (real)(obs->radius * obs->radius); }
+    if (obs) a.no_init = obs->state_estimator;
     a.B = dims->B; a.T = dims->T;
     a.z = (const real *)z; a.xnext = (const real *)xnext; a.F = (const real *)F; a.x0 = (const real *)x0;
     a.lam = (const real *)lam; a.rho = (const real *)rho; a.Qd = (const real *)Qd; a.q = (const real *)q;
     a.ulo = (const real *)u_lo; a.uhi = (const real *)u_hi; a.sb_u = sb_u; a.st_u = st_u;
     a.d_out = (real *)d_out; a.g_out = (real *)g_out; a.factor = (real *)factor_out; a.info = info;
     if (workspace) {   // quad variant: the factor stays in the workspace records (alqp_backward_ws)
-        if (a.nobs > 0 || factor_out) return ALQP_E_BADARG;
+        if (a.nobs > 0 || a.no_init || factor_out) return ALQP_E_BADARG;
         const size_t need = quad_ws_bytes<real>(dims->nx, dims->nu, dims->B, dims->T);
         if (need == 0) return ALQP_E_UNSUPPORTED;
         if (ws_bytes < need) return ALQP_E_BADARG;
@@ -1135,6 +1140,7 @@ int merit_impl(const AlqpDims *dims, int K, const void *zc, const void *xnext, c
     if (obs && (obs->nobs < 0 || (obs->nobs > 0 && (!obs->pos || dims->nx < 3)))) return ALQP_E_BADARG;
     AuxArgs<real> a = {};
     if (obs && obs->nobs > 0) { a.obs = (const real *)obs->pos; a.nobs = obs->nobs; a.obs_r2 = (real)(obs->radius * obs->radius); }
+    if (obs) a.no_init = obs->state_estimator;
     a.B = dims->B; a.T = dims->T; a.nx = dims->nx; a.nu = dims->nu; a.K = K;
     a.zc = (const real *)zc; a.xnext = (const real *)xnext; a.x0 = (const real *)x0;
     a.lam = (const real *)lam; a.rho = (const real *)rho; a.Qd = (const real *)Qd; a.q = (const real *)q;
@@ -1156,6 +1162,7 @@ int merit_pick_impl(const AlqpDims *dims, int n_ls, const void *d, const void *x
     if (obs && (obs->nobs < 0 || (obs->nobs > 0 && (!obs->pos || dims->nx < 3)))) return ALQP_E_BADARG;
     AuxArgs<real> a = {};
     if (obs && obs->nobs > 0) { a.obs = (const real *)obs->pos; a.nobs = obs->nobs; a.obs_r2 = (real)(obs->radius * obs->radius); }
+    if (obs) a.no_init = obs->state_estimator;
     a.B = dims->B; a.T = dims->T; a.nx = dims->nx; a.nu = dims->nu; a.n_ls = n_ls;
     a.d = (const real *)d; a.xnext = (const real *)xnext_all; a.x0 = (const real *)x0;
     a.lam = (const real *)lam; a.rho = (const real *)rho; a.Qd = (const real *)Qd; a.q = (const real *)q;
@@ -1186,6 +1193,7 @@ int dual_impl(const AlqpDims *dims, const void *z, const void *xnext, const void
     if (obs && (obs->nobs < 0 || (obs->nobs > 0 && (!obs->pos || dims->nx < 3)))) return ALQP_E_BADARG;
     AuxArgs<real> a = {};
     if (obs && obs->nobs > 0) { a.obs = (const real *)obs->pos; a.nobs = obs->nobs; a.obs_r2 = (real)(obs->radius * obs->radius); }
+    if (obs) a.no_init = obs->state_estimator;
     a.B = dims->B; a.T = dims->T; a.nx = dims->nx; a.nu = dims->nu;
     a.zc = (const real *)z; a.xnext = (const real *)xnext; a.x0 = (const real *)x0;
     a.ulo = (const real *)u_lo; a.uhi = (const real *)u_hi; a.sb_u = sb_u; a.st_u = st_u;
@@ -1421,7 +1429,7 @@ __global__ void k_exit_test(const double *sumsq, double *ctl, int mode, double t
 #if ALQP_BUILD_MAIN
 extern "C" {
 
-int alqp_abi_version(void) { return 5; }
+int alqp_abi_version(void) { return 6; }
 
 int alqp_dyn_pendulum1l_f32(long K, const void *x, const void *u, double h, const void *h_pt, void *xnext, void *F, void *stream) {
     return alqp::dyn_pendulum1l_impl<float>(K, x, u, h, h_pt, xnext, F, stream);

@@ -175,6 +175,7 @@ struct Team {
     const real *gobs;   // this instance's centres [T][nobs][3] (global memory)
     int nobs;
     real obs_r2;
+    bool no_init;       // state-estimator variant: no initial-state rows, zero cost gradient on u (al_utils_se.py:186-200, 300-310)
 
     // `lds_team` must not be provably wave-uniform (see the kernels): uniform LDS reads
     // get scalarised by the compiler into ds_read + v_readfirstlane + SGPR-spill chains.
@@ -204,7 +205,7 @@ struct Team {
         }
         info = 0;
         gxnext = nullptr;
-        gobs = nullptr; nobs = 0; obs_r2 = 0;
+        gobs = nullptr; nobs = 0; obs_r2 = 0; no_init = false;
         // constant zero rows / pads of the SYRK operands
         for (int e = li; e < RB * NXP; e += G) Ft[e] = 0;
         for (int e = li; e < RB * NP; e += G) Sb[e] = 0;
@@ -269,7 +270,7 @@ struct Team {
         real l[N], fa[N];
         real fbuf[FCH];
         // initial-state residual (eq row block T-1), al_utils.py:274
-        if (li < NX) req[(T - 1) * NX + li] = zs[li] - gx0[li];
+        if (li < NX) req[(T - 1) * NX + li] = no_init ? real(0) : zs[li] - gx0[li];
         fetch_F(0, fbuf);
         real Qn = isH ? gQd[hi] : real(0), qn = isH ? gq[hi] : real(0);
         real cn = isW ? (gxnext ? gxnext[wr] : gc[wr]) : real(0);
@@ -339,14 +340,17 @@ struct Team {
                 D = Qv;
                 if (hi < NX) {
                     int row = (t == 0) ? (T - 1) * NX + hi : (t - 1) * NX + hi;
-                    g += fma_(rho, req[row], la);
-                    D += rho;
+                    if (!(no_init && t == 0)) {
+                        g += fma_(rho, req[row], la);
+                        D += rho;
+                    }
                 } else {
                     int j = hi - NX;
                     real vu = zv - uhi(t, j), vl = -zv + ulo(t, j);
                     real au = vu >= 0 ? real(1) : real(0), al = vl >= 0 ? real(1) : real(0);
                     D = fma_(rho, au + al, D);
                     g += fma_(rho, vu > 0 ? vu : real(0), la) - fma_(rho, vl > 0 ? vl : real(0), lb);
+                    if (no_init) g = 0;   // the given controls carry no gradient (al_utils_se.py:300-310)
                 }
                 if (dyn) {
                     real s = 0;

@@ -50,6 +50,7 @@ from deq_mpc_corl_amd.qpth.al_utils import LinDx, QuadCost  # noqa: F401  (re-ex
 MAX_NEWTON = 4   # al_utils.py:485
 N_LS = 20        # al_utils.py:619
 RHO_SCALE = 10.0  # AL_mpc.py:325
+SE_NO_BOUND = 1e20  # state estimator: |u| bound that is never active (rho_max * SE_NO_BOUND is finite in fp32)
 
 
 def _detach_maybe(t):
@@ -123,8 +124,6 @@ class MPC(Module):
         super().__init__()
         if (u_lower is None) != (u_upper is None) or u_lower is None:
             raise ValueError("MPC: u_lower and u_upper are both required (AL_mpc.py:145,152)")
-        if state_estimator:
-            raise NotImplementedError("state_estimator=True (al_utils_se) is outside the hot path")
         if add_goal_constraint or ineqG is not None or not diag_cost:
             raise NotImplementedError("goal constraints / general inequalities / dense cost are "
                                       "not reachable from Tracking_MPC and are not built")
@@ -142,9 +141,11 @@ class MPC(Module):
         self.diag_cost = True
         self.linearize_once = False
         self.recompute_Qq = False
-        self.state_estimator = False
-        self.neq = n_state * T
-        self.nineq = 2 * n_ctrl * T
+        # state_estimator=True (AL_mpc.py:179-199 -> qpth/al_utils_se.py): the controls are GIVEN and only the
+        # states move; T-1 dynamics row blocks, no initial-state rows, no bound rows (lamda is [B, nx (T-1)]).
+        self.state_estimator = bool(state_estimator)
+        self.neq = n_state * (T - 1) if self.state_estimator else n_state * T
+        self.nineq = 0 if self.state_estimator else 2 * n_ctrl * T
         self.rho_prev = 1.0
         self.rho_max = 1e8
         self.dyn_res_prev = 1000000
@@ -276,8 +277,9 @@ class MPC(Module):
 
     # -- internals -------------------------------------------------------------------
     def _obs_kwargs(self, dtype, device):
-        """Extra backend arguments of the obstacle rows; the plain MPC has none."""
-        return {}
+        """Extra backend arguments describing the constraint-row set: obstacle rows (Obstacle_MPC), or the
+        state-estimator variant's set without initial-state rows; the plain MPC has none."""
+        return {"obs": "state_estimator"} if self.state_estimator else {}
 
     def _as_lindx(self, dx, B):
         """(F[B,T-1,nx,n], c[B,T-1,nx]) if `dx` carries affine data, else None."""
@@ -293,9 +295,14 @@ class MPC(Module):
         return F, c
 
     def _bounds(self, B, dtype, device):
+        nu = self.n_ctrl
+        if self.state_estimator:
+            # no bound rows in this variant (AL_mpc.py:198): bounds no control reaches keep the kernels' bound
+            # rows at residual 0 and multiplier 0 for every rho up to rho_max
+            big = torch.full((nu,), SE_NO_BOUND, dtype=dtype, device=device)
+            return -big, big, 0, 0
         lo = self.u_lower.to(device=device, dtype=dtype)
         hi = self.u_upper.to(device=device, dtype=dtype)
-        nu = self.n_ctrl
         if lo.dim() <= 1 and hi.dim() <= 1:
             lo = lo.reshape(-1).expand(nu).contiguous()
             hi = hi.reshape(-1).expand(nu).contiguous()
@@ -360,18 +367,21 @@ class MPC(Module):
         dev = x0.device
         if self.lamda_prev is None:
             self.lamda_prev = torch.zeros(B, self.neq + self.nineq, dtype=dt, device=dev)
+        nrows = self.n_state * self.T + 2 * self.n_ctrl * self.T   # the kernels' row layout
         st = _SolveState()
         st.mpc = self
         st.x0 = x0.detach().to(dt).contiguous()
         st.z = torch.cat((x, u), dim=2).detach().to(dt).contiguous().clone()
         st.lam = self.lamda_prev.detach().to(device=dev, dtype=dt).contiguous().clone()
+        if self.state_estimator:   # [B, nx (T-1)] -> the kernels' layout; the init and bound rows stay 0
+            st.lam = torch.cat((st.lam, st.lam.new_zeros(B, nrows - self.neq)), dim=1).contiguous()
         st.rho = self._rho_tensor(B, dt, dev)
         st.dx, st.dx_jac = dx, dx_jac
         st.lin = self._as_lindx(dx, B)
         st.stream_mode = stream_mode
         st.status_flag = False
         z = _ALSolve.apply(Qd.to(dt), q.to(dt), st)
-        self.lamda_prev = st.lam
+        self.lamda_prev = st.lam[:, :self.neq].contiguous() if self.state_estimator else st.lam
         self.rho_prev = st.rho.reshape(B, 1)
         self.just_initialized = False
         self.last_newton_per_al = st.newton_per_al
@@ -448,8 +458,10 @@ class MPC(Module):
         with torch.enable_grad():
             zz = z.detach().requires_grad_(True)
             xn_j, (A, Bm) = st.dx_jac(zz[:, :-1, :nx].reshape(-1, nx), zz[:, :-1, nx:].reshape(-1, nu))
-        F = torch.cat((A.detach().reshape(B, T - 1, nx, nx), Bm.detach().reshape(B, T - 1, nx, nu)),
-                      dim=-1).to(z.dtype).contiguous()
+        Bm = Bm.detach().reshape(B, T - 1, nx, nu)
+        if self.state_estimator:
+            Bm = Bm * 0.0   # the controls do not move (al_utils_se.py:151)
+        F = torch.cat((A.detach().reshape(B, T - 1, nx, nx), Bm), dim=-1).to(z.dtype).contiguous()
         return xn_j.detach().reshape(B, T - 1, nx).to(z.dtype).contiguous(), F
 
     def _newton_al_nonlin(self, st, Qd, q, bnd, ws, need_factor):
@@ -515,6 +527,13 @@ class MPC(Module):
                                "add it to ALQP_FOR_EACH_DIMS in csrc/alqp_kernels.hip")
         bnd = self._bounds(B, dt, dev)
         lo, hi, sb, stt = bnd
+        if self.state_estimator:
+            # cost gradient on the states only (al_utils_se.py:300-310) while the Hessian keeps diag(Q) on the
+            # controls (:66-68): the kernels' `state_estimator` flag. Their merit still counts the controls' cost
+            # terms, the same constant for every line-search candidate since du = 0 exactly (:31 leaves them out).
+            if torch.is_tensor(getattr(st.dx, "F", None)) or self.linearize_once:
+                raise NotImplementedError("state_estimator: only the callable dx / dx_jac route exists "
+                                          "(al_utils_se.py has no LinDx or frozen-linearisation branch)")
         ws = {"phi": torch.zeros(B, dtype=dt, device=dev), "rn2": torch.zeros(B, dtype=dt, device=dev),
               "info": torch.zeros(B, dtype=torch.int32, device=dev),
               "status": torch.ones(B, dtype=torch.uint8, device=dev)}

@@ -49,7 +49,12 @@ typedef struct AlqpDims {
 typedef struct AlqpObstacles {
     const void *pos;   /* DEVICE [B][T][nobs][3], the real type of the call */
     double radius;
-    int nobs;          /* reference: 4 nearest of 40 (AL_mpc_custom.py:52-54, 112-115) */
+    int nobs;          /* reference: 4 nearest of 40 (AL_mpc_custom.py:52-54, 112-115); 0: no obstacle rows */
+    int state_estimator; /* 1: the state-estimator variant (qpth/al_utils_se.py): no initial-state rows (row block
+                          T-1 of lam is ignored, x_0 gets no E'E term: :92-105, 186-200) and a cost gradient that is
+                          zero on the given controls (:300-310) while H keeps diag(Q) there (:66-68), so du = 0 exactly.
+                          The rest of that variant is data the caller prepares: B columns of F zeroed (:151), bounds
+                          out of reach (the variant has no bound rows, AL_mpc.py:198) */
 } AlqpObstacles;
 
 /* flags for alqp_solve_lin_* */

@@ -35,6 +35,11 @@ void FN(orc_set_obstacles)(const REAL *pos, int nobs, double radius)
 {
     FN(g_obs) = pos; FN(g_nobs) = pos ? nobs : 0; FN(g_obs_r2) = (REAL)(radius * radius);
 }
+/* State-estimator variant (qpth/al_utils_se.py:92-105, 186-200, 300-310): no initial-state rows - with the flag
+ * set the row block T-1 is identically zero (residual, multiplier update) and x_0 gets no E'E term - and the cost
+ * gradient on the (given) controls is zero while the Hessian keeps diag(Q) there (:66-68). */
+static int FN(g_no_init) = 0;
+void FN(orc_set_state_estimator)(int flag) { FN(g_no_init) = flag; }
 #define NOBS (FN(g_nobs))
 #define NINEQ_T (2 * nu + NOBS)                      /* inequality rows per stage */
 #define OBS_OF(b) (FN(g_obs) ? FN(g_obs) + (long)(b) * T * NOBS * 3 : (const REAL *)0)
@@ -52,7 +57,7 @@ static void FN(residual_one)(int T, int nx, int nu, const REAL *z, const REAL *x
         for (int i = 0; i < nx; ++i)
             res[t * nx + i] = z[(t + 1) * n + i] - xnext[t * nx + i];
     for (int i = 0; i < nx; ++i)
-        res[(T - 1) * nx + i] = z[i] - x0[i];
+        res[(T - 1) * nx + i] = FN(g_no_init) ? (REAL)0 : z[i] - x0[i];
     for (int t = 0; t < T; ++t)
         for (int j = 0; j < nu; ++j) {
             REAL u = z[t * n + nx + j];
@@ -135,6 +140,7 @@ static void FN(grad_hess_one)(int T, int nx, int nu, const REAL *z, const REAL *
         }
         /* E'E : x_t enters row block t-1 (t>=1) or the init rows (t=0) with identity */
         for (int i = 0; i < nx; ++i) {
+            if (t == 0 && FN(g_no_init)) break;
             H[i * n + i] += rho;
             int row = (t == 0) ? (T - 1) * nx + i : (t - 1) * nx + i;
             g[t * n + i] += lam[row] + rho * res[row];
@@ -165,6 +171,7 @@ static void FN(grad_hess_one)(int T, int nx, int nu, const REAL *z, const REAL *
             H[(nx + j) * n + nx + j] += rho * (au + al);
             g[t * n + nx + j] += (lam[ru] + rho * (vu > 0 ? vu : 0))
                                - (lam[rl] + rho * (vl > 0 ? vl : 0));
+            if (FN(g_no_init)) g[t * n + nx + j] = 0;   /* given controls: no gradient (al_utils_se.py:300-310) */
         }
         /* obstacle rows: J_k = -2 (p - o_k)' on the first three states; g += (lam_k + rho c_k+) J_k',
          * H += rho J_k'J_k for the rows with c_k >= 0 (al_utils.py:373-386, 113-120) */

@@ -99,6 +99,20 @@ class obstacles:
         _obs_keep.pop(self.dtype, None)
 
 
+class state_estimator:
+    """Context manager: the state-estimator variant (no initial-state rows, zero cost gradient on the controls)."""
+
+    def __init__(self, dtype, on=True):
+        self.dtype, self.on = dtype, bool(on)
+
+    def __enter__(self):
+        getattr(lib(), "orc_set_state_estimator_" + self.dtype)(int(self.on))
+        return self
+
+    def __exit__(self, *exc):
+        getattr(lib(), "orc_set_state_estimator_" + self.dtype)(0)
+
+
 def grad_hess(dtype, z, xnext, F, x0, lam, rho, Qd, q, ulo, uhi):
     dt = _np(dtype)
     B, T, n = z.shape

@@ -22,7 +22,7 @@ def names(pattern="*"):
     # dyn_*.npz and *casadi* belong to the dynamics-provider tests (tests/test_dynamics_provider.py)
     return sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, pattern + ".npz"))
                   if not os.path.basename(p).startswith("dyn_") and "casadi" not in os.path.basename(p)
-                  and "stream" not in os.path.basename(p) and not os.path.basename(p).startswith(("ip_", "obs_", "fail_")))
+                  and "stream" not in os.path.basename(p) and not os.path.basename(p).startswith(("ip_", "obs_", "fail_", "se_")))
 
 
 def step_context(g):

@@ -119,6 +119,8 @@ class OracleBackend:
     @staticmethod
     def _obs(s, obs):
         """Oracle context for the obstacle rows of Obstacle_MPC (obs = (centres [B,T,nobs,3], radius))."""
+        if isinstance(obs, str) and obs == "state_estimator":
+            return orc.state_estimator(s)
         return orc.obstacles(s, None if obs is None else _n(obs[0]), 0.0 if obs is None else obs[1])
 
     def newton_step(self, dims, z, xnext, F, x0, lam, rho, Qd, q, ulo, uhi, sb_u, st_u, d_out, g_out=None,

@@ -161,7 +161,8 @@ def test_unsupported_configurations_raise():
     from deq_mpc_corl_amd import MPC
     lo, hi = torch.tensor([-1.0]), torch.tensor([1.0])
     with pytest.raises(NotImplementedError):
-        MPC(2, 1, 5, u_lower=lo, u_upper=hi, state_estimator=True)
+        MPC(2, 1, 5, u_lower=lo, u_upper=hi, add_goal_constraint=True)
+    assert MPC(2, 1, 5, u_lower=lo, u_upper=hi, state_estimator=True).neq == 2 * 4   # tests/test_state_estimator_golden.py
     with pytest.raises(ValueError):
         MPC(2, 1, 5)
     with pytest.raises(ValueError):

@@ -1,0 +1,112 @@
+"""State-estimator variant (`AL_mpc.MPC(state_estimator=True)` -> qpth/al_utils_se.py) against
+fixtures made by RUNNING the reference (tools/gen_golden_se.py): the controls are given, only the states move,
+T-1 dynamics row blocks, no initial-state or bound rows.
+
+  * drop-in level: `deq_mpc_corl_amd.qpth.AL_mpc.MPC(state_estimator=True)` - Newton-step counts, lamda after
+    every AL iteration ([B, nx (T-1)], the reference's layout), rho, x, u (u returned unchanged), gradients w.r.t.
+    q and diag(Q) - on the CPU with the TEST-ONLY oracle backend and on the MI355X through the `_obs` entry
+    points with `AlqpObstacles.no_init_row = 1` (`-m gpu`).
+"""
+import numpy as np
+import pytest
+import torch
+
+from tests import golden_util as gu
+
+TD = {"f64": torch.float64, "f32": torch.float32}
+SE = ["se_pend_f64_al3", "se_cart_f64_al2", "se_quad13_f64_al2", "se_cart_f32_al2"]
+
+
+class _Dyn:
+    """Callable-only dynamics (no F / f attributes), like the torch-coded environments."""
+
+    def __init__(self, d):
+        self._d = d
+
+    def __call__(self, x, u):
+        return self._d(x, u)
+
+    def jac(self, x, u):
+        return self._d.jac(x, u)
+
+
+def _solve(g, backend, dev, al_iter, with_grad):
+    from deq_mpc_corl_amd import AffineDynamics, QuadCost
+    from deq_mpc_corl_amd.problems import PendulumDynamics
+    from deq_mpc_corl_amd.qpth.AL_mpc import MPC
+    dt = TD[g["dtype"]]
+    B, T, nx, nu = g["B"], g["T"], g["nx"], g["nu"]
+    tt = lambda a, d=dt: torch.as_tensor(np.ascontiguousarray(a)).to(d).to(dev)
+    dyn = _Dyn(PendulumDynamics() if str(g["kind"]) == "pendulum" else AffineDynamics(tt(g["F"]), tt(g["c"])))
+    mpc = MPC(nx, nu, T, u_lower=tt(g["u_lo"]), u_upper=tt(g["u_hi"]), n_batch=B, dtype=dt, state_estimator=True,
+              backend=backend)
+    mpc.reinitialize(tt(g["x0"]), None)
+    assert mpc.lamda_prev.shape == (B, nx * (T - 1))       # AL_mpc.py:186-199: no init rows, no bound rows
+    mpc.al_iter = al_iter
+    Qd, q = tt(g["Qd"]), tt(g["q"])
+    if with_grad:
+        Qd.requires_grad_(True)
+        q.requires_grad_(True)
+    z0 = tt(g["z0"])
+    x, u, st = mpc(tt(g["x0"]), QuadCost(torch.diag_embed(Qd), q, torch.zeros(B, T, dtype=dt, device=dev)), dyn, dyn.jac,
+                   x_init=z0[..., :nx].clone(), u_init=z0[..., nx:].clone())
+    return mpc, x, u, st, Qd, q
+
+
+def _replay(name, backend, dev):
+    g = gu.load(name)
+    f64 = g["dtype"] == "f64"
+    B, T, nx, nu = g["B"], g["T"], g["nx"], g["nu"]
+    c = lambda a: a.detach().cpu().numpy()
+    tt = lambda a, d: torch.as_tensor(np.ascontiguousarray(a)).to(d).to(dev)
+    with_grad = "bwd_q_grad" in g
+    mpc, x, u, st, Qd, q = _solve(g, backend, dev, g["al_iter"], with_grad)
+    assert st is False
+    assert list(mpc.last_newton_per_al) == g["newton_per_al"].tolist()
+    tol = 2e-6 if f64 else 2e-3
+    assert np.abs(c(x) - g["x"]).max() < tol * max(1.0, np.abs(g["x"]).max())
+    # the given controls come back untouched (du = 0 exactly; the float() cast is the reference's, AL_mpc.py:337)
+    assert np.array_equal(c(u), g["z0"][..., nx:].astype(np.float32))
+    assert np.array_equal(c(u), g["u"])
+    assert np.array_equal(c(mpc.rho_prev), g["rho_final"])
+    assert mpc.lamda_prev.shape == g["lam_final"].shape
+    ltol = 1e-7 if f64 else 5e-3
+    assert np.abs(c(mpc.lamda_prev) - g["lam_final"]).max() < ltol * max(1.0, np.abs(g["lam_final"]).max())
+    if with_grad:
+        (x * tt(g["bwd_wx"], torch.float32)).sum().backward()
+        assert np.abs(c(q.grad) - g["bwd_q_grad"]).max() < 1e-6 * np.abs(g["bwd_q_grad"]).max()
+        assert np.abs(c(Qd.grad) - g["bwd_Qd_grad"]).max() < 1e-6 * np.abs(g["bwd_Qd_grad"]).max()
+        assert np.abs(c(q.grad)[..., nx:]).max() == 0.0    # nothing flows to the controls' cost terms
+    if f64:   # lamda after every EARLIER AL iteration, by re-solving with fewer iterations
+        for k in range(1, g["al_iter"]):
+            m2 = _solve(g, backend, dev, k, False)[0]
+            assert list(m2.last_newton_per_al) == g["newton_per_al"].tolist()[:k]
+            assert np.abs(c(m2.lamda_prev) - g["lam_hist"][k - 1]).max() < ltol * max(1.0, np.abs(g["lam_hist"][k - 1]).max())
+
+
+@pytest.mark.parametrize("name", SE)
+def test_state_estimator_host_logic_cpu(name):
+    from tests.oracle_backend import OracleBackend
+    _replay(name, OracleBackend(), "cpu")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", SE)
+def test_state_estimator_hip(name):
+    _replay(name, None, "cuda:0")
+
+
+def test_state_estimator_rejects_affine_lindx():
+    """al_utils_se.py has no LinDx branch: fail loudly rather than run the wrong problem."""
+    from deq_mpc_corl_amd import LinDx, QuadCost
+    from deq_mpc_corl_amd.qpth.AL_mpc import MPC
+    from tests.oracle_backend import OracleBackend
+    g = gu.load("se_cart_f64_al2")
+    B, T, nx, nu = g["B"], g["T"], g["nx"], g["nu"]
+    t = lambda a: torch.as_tensor(np.ascontiguousarray(a))
+    mpc = MPC(nx, nu, T, u_lower=t(g["u_lo"]), u_upper=t(g["u_hi"]), n_batch=B, state_estimator=True, backend=OracleBackend())
+    mpc.reinitialize(t(g["x0"]), None)
+    z0 = t(g["z0"])
+    with pytest.raises(NotImplementedError):
+        mpc(t(g["x0"]), QuadCost(torch.diag_embed(t(g["Qd"])), t(g["q"]), torch.zeros(B, T)), LinDx(t(g["F"]), t(g["c"])), None,
+            x_init=z0[..., :nx].clone(), u_init=z0[..., nx:].clone())
