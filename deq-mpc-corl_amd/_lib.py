@@ -11,7 +11,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libmi_alqp.so")
+LIB_PATH = os.environ.get("MI_ALQP_LIB") or os.path.join(_HERE, "csrc", "libmi_alqp.so")   # MI_ALQP_LIB: A/B experiments with a second build of the same ABI
 
 ABI_VERSION = 6
 

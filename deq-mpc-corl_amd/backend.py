@@ -8,6 +8,8 @@ from __future__ import annotations
 
 import ctypes as C
 
+import os
+
 import torch
 
 from . import _lib
@@ -39,6 +41,10 @@ def _ptr(t, name, dtype=None, allow_none=False):
 
 def _stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+# experiments only (profiles/r02/experiments): bits 24-31 of AlqpParams.flags reach the quad kernel untouched
+_DEBUG_FLAGS = ((int(os.environ.get("ALQP_DEBUG_STAGGER", "0")) & 0xff) << 24) | ((int(os.environ.get("ALQP_DEBUG_STAGGER_CU", "0")) & 0xf) << 20)
 
 
 class HipBackend:
@@ -113,7 +119,7 @@ class HipBackend:
                 ws, ws_bytes = self._workspace(dims, z)
         self.last_variant = "quad" if vnum == 2 else "team"
         skp = _ptr(skip, "skip", torch.float64, True)
-        p = _lib.AlqpParams(al_iter, max_newton, n_ls, flags, rho_scale, vnum, skp.value if skp is not None else None)
+        p = _lib.AlqpParams(al_iter, max_newton, n_ls, flags | _DEBUG_FLAGS, rho_scale, vnum, skp.value if skp is not None else None)
         tr = None
         if trace is not None:
             tr = _lib.AlqpTrace(*[

@@ -244,6 +244,22 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     const int lane = threadIdx.x, qi = lane >> 2;
     const int b_raw = blockIdx.x * 16 + qi;
     const bool active = b_raw < a.B;
+    {
+        // experiment (flags bits 24-31, 0 in production): the wave on SIMD s of its CU starts s * stag * ~1024
+        // clocks late, so that the four waves of a CU are out of phase (memory phase of one under the
+        // arithmetic of the others) instead of marching in lock step
+        const int stag = (a.flags >> 24) & 0xff;
+        if (stag) {
+            const unsigned hw = __builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11));   // HW_REG_HW_ID
+            int simd = (hw >> 4) & 3;
+            const int mode = (a.flags >> 20) & 0xf;
+            if (mode == 1) simd = simd * 16 + ((hw >> 8) & 0xf);   // all 64 (SIMD, CU-in-array) pairs apart
+            if (mode == 2) simd &= 1;                              // two groups per CU
+            if (mode == 3) simd = blockIdx.x & 1;                  // two groups of XCDs
+            if (mode == 4) simd = (simd & 1) ^ (blockIdx.x & 1);   // two groups, mixed over SIMDs and XCDs
+            for (int i = 0; i < simd * stag; ++i) __builtin_amdgcn_s_sleep(16);
+        }
+    }
 #ifdef ALQP_ALIAS_ALL
     // experiment only (tools/phase_timing.sh -DALQP_ALIAS_ALL): every instance of an XCD-sized group
     // works on the same data, so the launch runs out of L2: what remains is the on-chip time
@@ -324,7 +340,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
                 if (tr.d && active) {
                     real *td = tr.d + ((size_t)step_id * a.B + b) * T * N;
                     for (int t = 0; t < T; ++t)
-                        for (int j = qd.q; j < N; j += 4) td[t * N + j] = qd.recp(t)[C::oY + j];
+                        for (int j = qd.q; j < N; j += 4) td[t * N + j] = qd.recp(t)[C::oY + C::pn(j)];
                 }
             }
             if constexpr (NL) qd.template merit_nonlin<Dyn>(ph);
@@ -413,7 +429,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
         real *Qg = a.Qd_grad + (size_t)b * T * N;
         for (int t = 0; t < T; ++t)
             for (int j = qd.q; j < N; j += 4) {
-                const real w = qd.recp(t)[C::oY + j];
+                const real w = qd.recp(t)[C::oY + C::pn(j)];
                 qg[t * N + j] = w;
                 Qg[t * N + j] = w * zf[t * N + j];
             }
@@ -469,7 +485,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
                 real cv = gxn[t * NX + r];
 #pragma unroll
                 for (int k = 0; k < N; ++k) cv = fma_(-W[s][k], zt[k], cv);
-                qd.recp(t)[C::oC + r] = cv;
+                qd.recp(t)[C::oC + C::px(r)] = cv;
             }
         }
     }
@@ -480,7 +496,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     if (active) {
         real *gd = a.d_out + (size_t)b * T * N;
         for (int t = 0; t < T; ++t)
-            for (int j = qd.q; j < N; j += 4) gd[t * N + j] = qd.recp(t)[C::oY + j];
+            for (int j = qd.q; j < N; j += 4) gd[t * N + j] = qd.recp(t)[C::oY + C::pn(j)];
         if (qd.q == 0 && a.info && qd.info && a.info[b] == 0) a.info[b] = qd.info;
     }
 }

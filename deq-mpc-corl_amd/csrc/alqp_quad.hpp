@@ -17,6 +17,10 @@
 // (Hh[k][j] = Lh[k][j] p_j, 1/p_j on the diagonal), y/d, r, s, and the stage's slice of
 // z, lam, diag Q, q, c and the bounds: everything a sweep needs apart from F_t sits in a
 // few whole 128-byte lines. stage_in() copies the slices in, iter_end() copies z, lam out.
+// The n- and nx-vectors of a record are stored LANE-MAJOR (element k = 4m + q at word q*SY + m):
+// the elements a lane owns are contiguous, so one 16-byte access (+ one word) moves them instead
+// of one word per instruction - the CU's vector-memory pipeline, shared by its four wavefronts,
+// is what this kernel queues on (profiles/r02/experiments/README.md).
 //
 // One Newton step = forward sweep (applies the pending line-search step, residual,
 // gradient, H_tt, right-looking LDL' panel, Schur complement for the next stage) +
@@ -199,6 +203,10 @@ struct QCfg {
     static constexpr int oq = oQ + 4 * SY;         // q_t
     static constexpr int oC = oq + 4 * SY;         // c_t
     static constexpr int RECW = (oC + 4 * SW + 31) & ~31;  // whole 128-byte lines (fp32)
+    // lane-major placement inside a vector field: element k of an n-vector (fields oY, oZ, oQ, oq; 4*SY words),
+    // row r of an nx-vector (fields oR, oS, oLE, oC; 4*SW words). Padding words hold zeros.
+    __host__ __device__ static constexpr int pn(int k) { return (k & 3) * SY + (k >> 2); }
+    __host__ __device__ static constexpr int px(int r) { return (r & 3) * SW + (r >> 2); }
     __host__ __device__ static constexpr int M(int T) { return T * NX + 2 * T * NU; }
     __host__ __device__ static constexpr size_t ws_words(int B, int T) { return (size_t)B * T * RECW; }
 };
@@ -244,6 +252,68 @@ struct Quad {
 #define ALQP_STAMP(b)
 #endif
 
+    // ---- lane-major vector fields of a record (QCfg::pn / px) ----
+    // own elements: k = 4m + q (m < SY) of an n-vector, rows r = 4s + q (s < SW) of an nx-vector;
+    // slots without an element read / write the field's zero padding
+    __device__ __forceinline__ void ld_own_n(const real *field, real (&v)[SY]) const { gload<SY>(field + q * SY, v); }
+    __device__ __forceinline__ void ld_own_x(const real *field, real (&v)[SW]) const { gload<SW>(field + q * SW, v); }
+    // x-part rows 4s + q of an n-vector (rows >= NX: whatever element 4s+q holds, finite)
+    __device__ __forceinline__ void ld_ownx_of_n(const real *field, real (&v)[SW]) const { gload<SW>(field + q * SY, v); }
+    template <int LEN>
+    __device__ __forceinline__ void gstore(real *p, const real (&v)[LEN]) const {
+#pragma unroll
+        for (int c = 0; c + 4 <= LEN; c += 4) gst4(p + c, v[c], v[c + 1], v[c + 2], v[c + 3]);
+#pragma unroll
+        for (int c = (LEN / 4) * 4; c < LEN; ++c) p[c] = v[c];
+    }
+    __device__ __forceinline__ void st_own_n(real *field, const real (&v)[SY]) const { gstore<SY>(field + q * SY, v); }
+    __device__ __forceinline__ void st_own_x(real *field, const real (&v)[SW]) const { gstore<SW>(field + q * SW, v); }
+    // every lane gets the whole vector (the 4*SY / 4*SW words are read by all four lanes alike)
+    __device__ __forceinline__ void ld_rep_n(const real *field, real (&v)[N]) const {
+        real w[4 * SY];
+        gload<4 * SY>(field, w);
+#pragma unroll
+        for (int k = 0; k < N; ++k) v[k] = w[C::pn(k)];
+    }
+    __device__ __forceinline__ void ld_repx_of_n(const real *field, real (&v)[NX]) const {   // x part of an n-vector
+        real w[4 * SY];
+        gload<4 * SY>(field, w);
+#pragma unroll
+        for (int k = 0; k < NX; ++k) v[k] = w[C::pn(k)];
+    }
+    __device__ __forceinline__ void ld_rep_x(const real *field, real (&v)[NX]) const {
+        real w[4 * SW];
+        gload<4 * SW>(field, w);
+#pragma unroll
+        for (int r = 0; r < NX; ++r) v[r] = w[C::px(r)];
+    }
+    // own elements out of a vector every lane holds (k = 4m + q; 0 where there is none)
+    template <int LEN, int SL>
+    __device__ __forceinline__ void own_of(const real (&full)[LEN], real (&v)[SL]) const {
+#pragma unroll
+        for (int m = 0; m < SL; ++m)
+            v[m] = (4 * m < LEN) ? sel4(full[(4 * m < LEN) ? 4 * m : 0], (4 * m + 1 < LEN) ? full[(4 * m + 1 < LEN) ? 4 * m + 1 : 0] : real(0),
+                                        (4 * m + 2 < LEN) ? full[(4 * m + 2 < LEN) ? 4 * m + 2 : 0] : real(0),
+                                        (4 * m + 3 < LEN) ? full[(4 * m + 3 < LEN) ? 4 * m + 3 : 0] : real(0), q)
+                                 : real(0);
+    }
+    // caller's contiguous array -> own elements (0 where there is none) and back
+    template <int LEN, int SL>
+    __device__ __forceinline__ void ld_own_ext(const real *src, real (&v)[SL]) const {
+#pragma unroll
+        for (int m = 0; m < SL; ++m) {
+            const int k = 4 * m + q;
+            const real x = src[(4 * m + 3 < LEN || k < LEN) ? k : LEN - 1];
+            v[m] = (4 * m + 3 < LEN || k < LEN) ? x : real(0);
+        }
+    }
+    template <int LEN, int SL>
+    __device__ __forceinline__ void st_own_ext(real *dst, const real (&v)[SL]) const {
+#pragma unroll
+        for (int m = 0; m < SL; ++m)
+            if (4 * m + 3 < LEN || 4 * m + q < LEN) dst[4 * m + q] = v[m];
+    }
+
     // F_t rows of this lane: row 4s+q (zeros for rows >= NX). Loads are unconditional (row
     // index clamped, result masked) so that all of a stage's loads go out in one batch:
     // a load inside a divergent branch cannot be hoisted and costs its own round trip.
@@ -287,31 +357,44 @@ struct Quad {
             const bool dyn = t < T - 1;
             real *rp = recp(t);
             if (active) {
-                copy_slice<N>(gz + t * N, rp + C::oZ);
-                copy_slice<N>(gQd + t * N, rp + C::oQ);
-                copy_slice<N>(gq + t * N, rp + C::oq);
-                copy_slice<NX>(glam + t * NX, rp + C::oLE);
+                real vn[SY], vx[SW];
+                ld_own_ext<N>(gz + t * N, vn);
+                st_own_n(rp + C::oZ, vn);
+                ld_own_ext<N>(gQd + t * N, vn);
+                st_own_n(rp + C::oQ, vn);
+                ld_own_ext<N>(gq + t * N, vn);
+                st_own_n(rp + C::oq, vn);
+                ld_own_ext<NX>(glam + t * NX, vx);
+                st_own_x(rp + C::oLE, vx);
                 copy_slice<2 * NU>(glam + T * NX + t * 2 * NU, rp + C::oLU);
                 copy_slice<NU>(guhi + t * st_u, rp + C::oBU);
                 copy_slice<NU>(gulo + t * st_u, rp + C::oBL);
-                if (dyn && have_c) copy_slice<NX>(gc + t * NX, rp + C::oC);
+                if (dyn && have_c) ld_own_ext<NX>(gc + t * NX, vx);
+                else {
+#pragma unroll
+                    for (int s = 0; s < SW; ++s) vx[s] = 0;
+                }
+                if (have_c) st_own_x(rp + C::oC, vx);
             }
             if (with_residual) {
                 WT W = wpanel();
                 real zt[N];
                 load_F_rows(dyn ? t : (T > 1 ? T - 2 : 0), W);
                 gload<N>(gz + t * N, zt);
+                real rr[SW];
 #pragma unroll
                 for (int s = 0; s < SW; ++s) {
                     const int r = 4 * s + q;
-                    if ((4 * s + 3 < NX || r < NX) && active) {
+                    rr[s] = 0;
+                    if (4 * s + 3 < NX || r < NX) {
                         real xn = dyn ? gc[t * NX + r] : real(0);
 #pragma unroll
                         for (int k = 0; k < N; ++k) xn = fma_(W[s][k], zt[k], xn);
                         // row block T-1 holds the initial-state rows x_0 - x_init (al_utils.py:274)
-                        rp[C::oR + r] = dyn ? gz[(t + 1) * N + r] - xn : gz[r] - gx0[r];
+                        rr[s] = dyn ? gz[(t + 1) * N + r] - xn : gz[r] - gx0[r];
                     }
                 }
+                if (active) st_own_x(rp + C::oR, rr);
             }
         }
     }
@@ -321,8 +404,11 @@ struct Quad {
 #pragma unroll 2
         for (int t = 0; t < T; ++t) {
             const real *rp = recp(t);
-            copy_slice<N>(rp + C::oZ, gz + t * N);
-            copy_slice<NX>(rp + C::oLE, glam + t * NX);
+            real vn[SY], vx[SW];
+            ld_own_n(rp + C::oZ, vn);
+            st_own_ext<N>(gz + t * N, vn);
+            ld_own_x(rp + C::oLE, vx);
+            st_own_ext<NX>(glam + t * NX, vx);
             copy_slice<2 * NU>(rp + C::oLU, glam + T * NX + t * 2 * NU);
         }
     }
@@ -341,40 +427,34 @@ struct Quad {
             real *rp = recp(t);
             const real *rn = recp(dyn ? t + 1 : t);
             real zt[N], dt[N], zn[SW], dn[SW];
-            gload<N>(rp + C::oZ, zt);
-            gload<N>(rp + C::oY, dt);
-#pragma unroll
-            for (int s = 0; s < SW; ++s) {
-                const int rc = (4 * s + q < NX) ? 4 * s + q : NX - 1;
-                zn[s] = rn[C::oZ + rc];
-                dn[s] = rn[C::oY + rc];
-            }
+            ld_rep_n(rp + C::oZ, zt);
+            ld_rep_n(rp + C::oY, dt);
+            ld_ownx_of_n(rn + C::oZ, zn);
+            ld_ownx_of_n(rn + C::oY, dn);
             if (pend) {
 #pragma unroll
                 for (int k = 0; k < N; ++k) zt[k] = fma_(alpha, dt[k], zt[k]);
 #pragma unroll
                 for (int s = 0; s < SW; ++s) zn[s] = fma_(alpha, dn[s], zn[s]);
                 if (active) {
-#pragma unroll
-                    for (int m = 0; m < SY; ++m) {
-                        const real zv = sel4(zt[4 * m], (4 * m + 1 < N) ? zt[(4 * m + 1 < N) ? 4 * m + 1 : 0] : real(0),
-                                             (4 * m + 2 < N) ? zt[(4 * m + 2 < N) ? 4 * m + 2 : 0] : real(0),
-                                             (4 * m + 3 < N) ? zt[(4 * m + 3 < N) ? 4 * m + 3 : 0] : real(0), q);
-                        if (4 * m + 3 < N || 4 * m + q < N) rp[C::oZ + 4 * m + q] = zv;
-                    }
+                    real zo[SY];
+                    own_of<N, SY>(zt, zo);
+                    st_own_n(rp + C::oZ, zo);
                 }
             }
             if (t == 0) {
                 // initial-state rows x_0 - x_init live in row block T-1 (al_utils.py:274); a merit
                 // evaluation may come before the first forward sweep rewrites them
+                real r0[SW];
 #pragma unroll
                 for (int s = 0; s < SW; ++s) {
                     const int r = 4 * s + q;
                     const real z0r = sel4(zt[4 * s], (4 * s + 1 < NX) ? zt[(4 * s + 1 < NX) ? 4 * s + 1 : 0] : real(0),
                                           (4 * s + 2 < NX) ? zt[(4 * s + 2 < NX) ? 4 * s + 2 : 0] : real(0),
                                           (4 * s + 3 < NX) ? zt[(4 * s + 3 < NX) ? 4 * s + 3 : 0] : real(0), q);
-                    if ((4 * s + 3 < NX || r < NX) && active) recp(T - 1)[C::oR + r] = z0r - gx0[(r < NX) ? r : NX - 1];
+                    r0[s] = (4 * s + 3 < NX || r < NX) ? z0r - gx0[(r < NX) ? r : NX - 1] : real(0);
                 }
+                if (active) st_own_x(recp(T - 1) + C::oR, r0);
             }
             if (dyn) {
                 // the quad's lanes split the n tangents (lane q: columns 4i+q), then row 4s+q of J is
@@ -382,6 +462,7 @@ struct Quad {
                 constexpr int NTL = (N + 3) / 4;
                 real xn[NX], Jl[NX][NTL];
                 dyn_value_jac_split<Dyn, real>(zt, dyn_h, q, xn, Jl);
+                real co[SW], ro[SW];
 #pragma unroll
                 for (int s = 0; s < SW; ++s) {
                     const int r = 4 * s + q;
@@ -398,13 +479,18 @@ struct Quad {
                     real c = xr;
 #pragma unroll
                     for (int k = 0; k < N; ++k) c = fma_(-Jr[k], zt[k], c);
-                    if ((4 * s + 3 < NX || r < NX) && active) {
+                    const bool okr = 4 * s + 3 < NX || r < NX;
+                    if (okr && active) {
                         real *Fr = gFw + ((size_t)t * NX + r) * N;
 #pragma unroll
                         for (int k = 0; k < N; ++k) Fr[k] = Jr[k];
-                        rp[C::oC + r] = c;
-                        rp[C::oR + r] = zn[s] - xr;
                     }
+                    co[s] = okr ? c : real(0);
+                    ro[s] = okr ? zn[s] - xr : real(0);
+                }
+                if (active) {
+                    st_own_x(rp + C::oC, co);
+                    st_own_x(rp + C::oR, ro);
                 }
             }
         }
@@ -418,19 +504,19 @@ struct Quad {
         for (int i = 0; i < 5; ++i) m[i] = 0;
         real x0v[NX], li[NX];
         gload<NX>(gx0, x0v);
-        gload<NX>(recp(T - 1) + C::oLE, li);
+        ld_rep_x(recp(T - 1) + C::oLE, li);
         const real a0 = sel4(real(1), real(0.5), real(0.25), real(0.125), q);
         for (int t = 0; t < T; ++t) {
             const bool dyn = t < T - 1;
             const real *rp = recp(t), *rn = recp(dyn ? t + 1 : t);
             real zt[N], dt[N], Qt[N], qt[N], zn[NX], dn[NX], le[NX], lu[NU], ll[NU], bu[NU], bl[NU];
-            gload<N>(rp + C::oZ, zt);
-            gload<N>(rp + C::oY, dt);
-            gload<N>(rp + C::oQ, Qt);
-            gload<N>(rp + C::oq, qt);
-            gload<NX>(rn + C::oZ, zn);
-            gload<NX>(rn + C::oY, dn);
-            gload<NX>(rp + C::oLE, le);
+            ld_rep_n(rp + C::oZ, zt);
+            ld_rep_n(rp + C::oY, dt);
+            ld_rep_n(rp + C::oQ, Qt);
+            ld_rep_n(rp + C::oq, qt);
+            ld_repx_of_n(rn + C::oZ, zn);
+            ld_repx_of_n(rn + C::oY, dn);
+            ld_rep_x(rp + C::oLE, le);
             gload<NU>(rp + C::oLU, lu);
             gload<NU>(rp + C::oLU + NU, ll);
             gload<NU>(rp + C::oBU, bu);
@@ -492,13 +578,13 @@ struct Quad {
         for (int s = 0; s < SW; ++s) Sy[s] = 0;
         // stage 0: x_0 is pinned by the initial-state rows (eq row block T-1), al_utils.py:274
         {
-            real z0[NX], xi[NX], li[NX];
-            gload<NX>(recp(0) + C::oZ, z0);
+            real z0[NX], xi[NX], li[NX], r0[NX];
+            ld_repx_of_n(recp(0) + C::oZ, z0);
             gload<NX>(gx0, xi);
-            gload<NX>(recp(T - 1) + C::oLE, li);
+            ld_rep_x(recp(T - 1) + C::oLE, li);
             if (pending) {
                 real d0[NX];
-                gload<NX>(recp(0) + C::oY, d0);
+                ld_repx_of_n(recp(0) + C::oY, d0);
 #pragma unroll
                 for (int j = 0; j < NX; ++j) z0[j] = fma_(alpha, d0[j], z0[j]);
             }
@@ -508,7 +594,12 @@ struct Quad {
                 vprev[j] = fma_(rho, r, li[j]);
                 if constexpr (C::PHI0_FWD) mrep = fma_(fma_(real(0.5) * rho, r, li[j]), r, mrep);  // initial-state rows
                 Syrep[j] = 0;
-                if ((j & 3) == q && active) recp(T - 1)[C::oR + j] = r;
+                r0[j] = r;
+            }
+            if (active) {
+                real ro[SW];
+                own_of<NX, SW>(r0, ro);
+                st_own_x(recp(T - 1) + C::oR, ro);
             }
         }
         for (int t = 0; t < T; ++t) {
@@ -525,51 +616,39 @@ struct Quad {
                 real zt[N], Qt[N], qt[N];
                 real cs[SW], zn[SW], lm[SW];
                 real lu[NU], ll[NU], bu[NU], bl[NU];
-                gload<N>(rp + C::oZ, zt);
+                ld_rep_n(rp + C::oZ, zt);
                 real Qo[SY], qo[SY];  // fp64: own elements only, broadcast where used (48 registers less)
                 if constexpr (C::S_AFTER) {
-#pragma unroll
-                    for (int m = 0; m < SY; ++m) {
-                        const int jc = (4 * m + q < N) ? 4 * m + q : N - 1;
-                        Qo[m] = rp[C::oQ + jc];
-                        qo[m] = rp[C::oq + jc];
-                    }
+                    ld_own_n(rp + C::oQ, Qo);
+                    ld_own_n(rp + C::oq, qo);
                 } else {
-                    gload<N>(rp + C::oQ, Qt);
-                    gload<N>(rp + C::oq, qt);
+                    ld_rep_n(rp + C::oQ, Qt);
+                    ld_rep_n(rp + C::oq, qt);
                 }
                 const int td = dyn ? t : (T > 1 ? T - 2 : 0);  // valid addresses for the last stage
                 load_F_rows(td, W);
                 const real *rn = recp(td + 1);
-#pragma unroll
-                for (int s = 0; s < SW; ++s) {
-                    const int r = 4 * s + q, rc = r < NX ? r : NX - 1;
-                    cs[s] = rp[C::oC + rc];
-                    zn[s] = rn[C::oZ + rc];
-                    lm[s] = rp[C::oLE + rc];
-                }
+                ld_own_x(rp + C::oC, cs);
+                ld_ownx_of_n(rn + C::oZ, zn);
+                ld_own_x(rp + C::oLE, lm);
                 gload<NU>(rp + C::oLU, lu);
                 gload<NU>(rp + C::oLU + NU, ll);
                 gload<NU>(rp + C::oBU, bu);
                 gload<NU>(rp + C::oBL, bl);
                 if (pending) {  // wave-uniform: z_t += alpha d_t, z_{t+1}[x] += alpha d_{t+1}[x]
                     real dt[N], dn[SW];
-                    gload<N>(rp + C::oY, dt);
-#pragma unroll
-                    for (int s = 0; s < SW; ++s) dn[s] = rn[C::oY + ((4 * s + q < NX) ? 4 * s + q : NX - 1)];
+                    ld_rep_n(rp + C::oY, dt);
+                    ld_ownx_of_n(rn + C::oY, dn);
 #pragma unroll
                     for (int k = 0; k < N; ++k) zt[k] = fma_(alpha, dt[k], zt[k]);
 #pragma unroll
                     for (int s = 0; s < SW; ++s) zn[s] = fma_(alpha, dn[s], zn[s]);
                     // own elements of the advanced z_t; written with the stage results below (a
                     // store here would sit between the loads and their counted waits)
-#pragma unroll
-                    for (int m = 0; m < SY; ++m)
-                        zs[m] = sel4(zt[4 * m], (4 * m + 1 < N) ? zt[(4 * m + 1 < N) ? 4 * m + 1 : 0] : real(0),
-                                     (4 * m + 2 < N) ? zt[(4 * m + 2 < N) ? 4 * m + 2 : 0] : real(0),
-                                     (4 * m + 3 < N) ? zt[(4 * m + 3 < N) ? 4 * m + 3 : 0] : real(0), q);
+                    own_of<N, SY>(zt, zs);
                 }
                 ALQP_STAMP(0);  // forward: exposed load latency
+                real rro[SW];
                 if (!dyn) {
 #pragma unroll
                     for (int s = 0; s < SW; ++s)
@@ -585,9 +664,10 @@ struct Quad {
                     const real rr = zn[s] - xn;
                     const bool ok = dyn && r < NX;
                     v[s] = ok ? fma_(rho, rr, lm[s]) : real(0);
-                    if (ok && active) rp[C::oR + r] = rr;
+                    rro[s] = ok ? rr : real(0);
                     if constexpr (C::PHI0_FWD) mdist += ok ? fma_(fma_(real(0.5) * rho, rr, lm[s]), rr, real(0)) : real(0);
                 }
+                if (dyn && active) st_own_x(rp + C::oR, rro);
                 // ---- gradient (replicated in the 4 lanes) and diagonal of H_tt
 #pragma unroll
                 for (int j = 0; j < N; ++j) {
@@ -712,16 +792,12 @@ struct Quad {
                         if (C::lanes_of(s) == 4 || q < C::lanes_of(s))
                             gst4(rp + C::oL + C::lbase(s) + c * 4 * C::lanes_of(s) + 4 * q, H[C::hidx(s, 4 * c)],
                                  H[C::hidx(s, 4 * c + 1)], H[C::hidx(s, 4 * c + 2)], H[C::hidx(s, 4 * c + 3)]);
-#pragma unroll
-                for (int j = 0; j < N; ++j)
-                    if ((j & 3) == q) rp[C::oY + j] = Y[j];
-                if (pending) {
-#pragma unroll
-                    for (int m = 0; m < SY; ++m)
-                        if (4 * m + 3 < N || 4 * m + q < N) rp[C::oZ + 4 * m + q] = zs[m];
-                }
+                real yo[SY];
+                own_of<N, SY>(Y, yo);
+                st_own_n(rp + C::oY, yo);
+                if (pending) st_own_n(rp + C::oZ, zs);
             }
-        
+
             if constexpr (C::S_AFTER) {
                 // fp64: the Schur complement of this stage once the factor's registers are free
                 if (dyn) {
@@ -781,8 +857,7 @@ struct Quad {
                          H[C::hidx(s, 4 * c + 1)], H[C::hidx(s, 4 * c + 2)], H[C::hidx(s, 4 * c + 3)]);
                 }
             real yo[SY];
-#pragma unroll
-            for (int m = 0; m < SY; ++m) yo[m] = (4 * m + q < N) ? rp[C::oY + 4 * m + q] : real(0);
+            ld_own_n(rp + C::oY, yo);
             real Y[N];
 #pragma unroll
             for (int j = 0; j < N; ++j) Y[j] = qbv(yo[j >> 2], j);
@@ -790,12 +865,12 @@ struct Quad {
             load_F_rows(dyn ? t : (T > 1 ? T - 2 : 0), W);  // same batch as the record loads
             real zz[SY], QQ[SY], qq[SY], lu[SY], ll[SY], bu[SY], bl[SY], rv[SW], lv[SW];
             if constexpr (LS) {
+                ld_own_n(rp + C::oZ, zz);
+                ld_own_n(rp + C::oQ, QQ);
+                ld_own_n(rp + C::oq, qq);
 #pragma unroll
                 for (int m = 0; m < SY; ++m) {
                     const int j = 4 * m + q, jc = (4 * m + 3 < N) ? j : (j < N ? j : N - 1);
-                    zz[m] = rp[C::oZ + jc];
-                    QQ[m] = rp[C::oQ + jc];
-                    qq[m] = rp[C::oq + jc];
                     if (m >= MU0) {
                         const int ju = jc >= NX ? jc - NX : 0;
                         lu[m] = rp[C::oLU + ju];
@@ -804,12 +879,8 @@ struct Quad {
                         bl[m] = rp[C::oBL + ju];
                     }
                 }
-#pragma unroll
-                for (int s = 0; s < SW; ++s) {
-                    const int r = 4 * s + q, rc = (4 * s + 3 < NX) ? r : (r < NX ? r : NX - 1);
-                    rv[s] = rp[C::oR + rc];
-                    lv[s] = rp[C::oLE + rc];
-                }
+                ld_own_x(rp + C::oR, rv);
+                ld_own_x(rp + C::oLE, lv);
             }
             ALQP_STAMP(4);  // backward: exposed load latency
             real dxs[SW];
@@ -847,9 +918,9 @@ struct Quad {
                 for (int j = 0; j < i; ++j) Y[j] = fma_(-qbv(H[C::hidx(i >> 2, j)], i), di, Y[j]);
             }
             if (active) {
-#pragma unroll
-                for (int j = 0; j < N; ++j)
-                    if ((j & 3) == q) rp[C::oY + j] = Y[j];
+                real down[SY];
+                own_of<N, SY>(Y, down);
+                st_own_n(rp + C::oY, down);
             }
             real sv[SW];
 #pragma unroll
@@ -861,9 +932,9 @@ struct Quad {
                     real p = 0;
 #pragma unroll
                     for (int k = 0; k < N; ++k) p = fma_(W[s][k], Y[k], p);
-                    sv[s] = dxs[s] - p;
-                    if (r < NX && active) rp[C::oS + r] = sv[s];
+                    sv[s] = (4 * s + 3 < NX || r < NX) ? dxs[s] - p : real(0);
                 }
+                if (active) st_own_x(rp + C::oS, sv);
             }
             if constexpr (LS) {
 #pragma unroll
@@ -914,9 +985,11 @@ struct Quad {
             ALQP_STAMP(5);  // backward: solves + stores
         }
         // initial-state rows: s = d_0[x]
-#pragma unroll
-        for (int j = 0; j < NX; ++j)
-            if ((j & 3) == q && active) recp(T - 1)[C::oS + j] = dxn[j];
+        if (active) {
+            real so[SW];
+            own_of<NX, SW>(dxn, so);
+            st_own_x(recp(T - 1) + C::oS, so);
+        }
         if constexpr (LS) {
 #pragma unroll
             for (int s = 0; s < SW; ++s) {
@@ -987,9 +1060,9 @@ struct Quad {
                 for (int k = j + 1; k < N; ++k) Y[k] = fma_(-qbv(H[C::hidx(k >> 2, j)], k), yj, Y[k]);
             }
             if (active) {
-#pragma unroll
-                for (int j = 0; j < N; ++j)
-                    if ((j & 3) == q) rp[C::oY + j] = Y[j];
+                real yo[SY];
+                own_of<N, SY>(Y, yo);
+                st_own_n(rp + C::oY, yo);
             }
             // e = Lh^{-T} D^{-1} u for the coupling of the next stage
 #pragma unroll
@@ -1020,13 +1093,13 @@ struct Quad {
             real zz[SY], dd[SY], QQ[SY], qq[SY];
             real rv[SW], sv[SW], lv[SW];
             real lu[SY], ll[SY], bu[SY], bl[SY];
+            ld_own_n(rp + C::oZ, zz);
+            ld_own_n(rp + C::oY, dd);
+            ld_own_n(rp + C::oQ, QQ);
+            ld_own_n(rp + C::oq, qq);
 #pragma unroll
             for (int m = 0; m < SY; ++m) {
                 const int j = 4 * m + q, jc = (4 * m + 3 < N) ? j : (j < N ? j : N - 1);
-                zz[m] = rp[C::oZ + jc];
-                dd[m] = rp[C::oY + jc];
-                QQ[m] = rp[C::oQ + jc];
-                qq[m] = rp[C::oq + jc];
                 if (m >= MU0) {
                     const int ju = jc >= NX ? jc - NX : 0;
                     lu[m] = rp[C::oLU + ju];
@@ -1035,13 +1108,9 @@ struct Quad {
                     bl[m] = rp[C::oBL + ju];
                 }
             }
-#pragma unroll
-            for (int s = 0; s < SW; ++s) {
-                const int r = 4 * s + q, rc = (4 * s + 3 < NX) ? r : (r < NX ? r : NX - 1);
-                rv[s] = rp[C::oR + rc];
-                sv[s] = rp[C::oS + rc];
-                lv[s] = rp[C::oLE + rc];
-            }
+            ld_own_x(rp + C::oR, rv);
+            ld_own_x(rp + C::oS, sv);
+            ld_own_x(rp + C::oLE, lv);
 #pragma unroll
             for (int m = 0; m < SY; ++m) {
                 const int j = 4 * m + q;
@@ -1105,13 +1174,13 @@ struct Quad {
             real zz[SY], dd[SY], QQ[SY], qq[SY];
             real rv[SW], sv[SW], lv[SW];
             real lu[SY], ll[SY], bu[SY], bl[SY];
+            ld_own_n(rp + C::oZ, zz);
+            ld_own_n(rp + C::oY, dd);
+            ld_own_n(rp + C::oQ, QQ);
+            ld_own_n(rp + C::oq, qq);
 #pragma unroll
             for (int m = 0; m < SY; ++m) {
                 const int j = 4 * m + q, jc = (4 * m + 3 < N) ? j : (j < N ? j : N - 1);
-                zz[m] = rp[C::oZ + jc];
-                dd[m] = rp[C::oY + jc];
-                QQ[m] = rp[C::oQ + jc];
-                qq[m] = rp[C::oq + jc];
                 if (m >= MU0) {
                     const int ju = jc >= NX ? jc - NX : 0;
                     lu[m] = rp[C::oLU + ju];
@@ -1120,13 +1189,9 @@ struct Quad {
                     bl[m] = rp[C::oBL + ju];
                 }
             }
-#pragma unroll
-            for (int s = 0; s < SW; ++s) {
-                const int r = 4 * s + q, rc = (4 * s + 3 < NX) ? r : (r < NX ? r : NX - 1);
-                rv[s] = rp[C::oR + rc];
-                sv[s] = rp[C::oS + rc];
-                lv[s] = rp[C::oLE + rc];
-            }
+            ld_own_x(rp + C::oR, rv);
+            ld_own_x(rp + C::oS, sv);
+            ld_own_x(rp + C::oLE, lv);
             real rtrue[SW];
 #pragma unroll
             for (int s = 0; s < SW; ++s) rtrue[s] = 0;
@@ -1134,18 +1199,20 @@ struct Quad {
                 if (t < T - 1) {
                     const real *rn_ = recp(t + 1);
                     real zr[N], dr[N], xn[NX];
-                    gload<N>(rp + C::oZ, zr);
-                    gload<N>(rp + C::oY, dr);
+                    ld_rep_n(rp + C::oZ, zr);
+                    ld_rep_n(rp + C::oY, dr);
                     if (pend) {
 #pragma unroll
                         for (int k = 0; k < N; ++k) zr[k] = fma_(alpha, dr[k], zr[k]);
                     }
                     dyn_value<Dyn, real>(zr, dyn_h, xn);
+                    real zno[SW], dno[SW];
+                    ld_ownx_of_n(rn_ + C::oZ, zno);
+                    ld_ownx_of_n(rn_ + C::oY, dno);
 #pragma unroll
                     for (int s = 0; s < SW; ++s) {
-                        const int rc = (4 * s + q < NX) ? 4 * s + q : NX - 1;
-                        real znn = rn_[C::oZ + rc];
-                        const real dnn = rn_[C::oY + rc];
+                        real znn = zno[s];
+                        const real dnn = dno[s];
                         if (pend) znn = fma_(alpha, dnn, znn);
                         const real xr = sel4(xn[4 * s], (4 * s + 1 < NX) ? xn[(4 * s + 1 < NX) ? 4 * s + 1 : 0] : real(0),
                                              (4 * s + 2 < NX) ? xn[(4 * s + 2 < NX) ? 4 * s + 2 : 0] : real(0),
@@ -1159,11 +1226,11 @@ struct Quad {
                 const int j = 4 * m + q;
                 const bool valid = 4 * m + 3 < N || j < N;
                 const real ok = valid ? real(1) : real(0);
-                const real z = pend ? fma_(alpha, dd[m], zz[m]) : zz[m];
+                const real z = valid ? (pend ? fma_(alpha, dd[m], zz[m]) : zz[m]) : real(0);
                 const real Qv = QQ[m] * ok, qv = qq[m] * ok;
                 if (valid) bad |= !(z - z == real(0));
+                zz[m] = z;
                 if (valid && active) {
-                    if (pend) rp[C::oZ + j] = z;
                     if (write_out) gz[t * N + j] = z;
                 }
                 c0 = fma_(fma_(real(0.5) * Qv, z, qv), z, c0);
@@ -1193,6 +1260,7 @@ struct Quad {
                     r2 = fma_(isu, fma_(cu, cu, cl * cl), r2);
                 }
             }
+            if (pend && active) st_own_n(rp + C::oZ, zz);
 #pragma unroll
             for (int s = 0; s < SW; ++s) {
                 const int r = 4 * s + q;
@@ -1202,15 +1270,20 @@ struct Quad {
                 if constexpr (Dyn::ID != 0) {
                     if (t < T - 1) rn = rtrue[s];
                 }
-                const real ln = dual ? fma_(rho, rn, lv[s]) : lv[s];
+                if (!valid) rn = 0;
+                const real ln = valid ? (dual ? fma_(rho, rn, lv[s]) : lv[s]) : real(0);
+                rv[s] = rn;
+                lv[s] = ln;
                 if (valid && active) {
-                    if (pend || Dyn::ID != 0) rp[C::oR + r] = rn;
-                    if (dual) rp[C::oLE + r] = ln;
                     if (write_out) glam[t * NX + r] = ln;
                 }
                 const real rr = rn * ok, lm = ln * ok;
                 c0 = fma_(fma_(real(0.5) * rho_n, rr, lm), rr, c0);
                 r2 = fma_(rr, rr, r2);
+            }
+            if (active) {
+                if (pend || Dyn::ID != 0) st_own_x(rp + C::oR, rv);
+                if (dual) st_own_x(rp + C::oLE, lv);
             }
         }
         rho = rho_n;
@@ -1224,16 +1297,19 @@ struct Quad {
         real acc = 0;
         for (int t = 0; t < T; ++t) {
             const real *rp = recp(t);
+            real ro[SW], zo[SY];
+            ld_own_x(rp + C::oR, ro);
+            ld_own_n(rp + C::oZ, zo);
 #pragma unroll
             for (int s = 0; s < SW; ++s) {
                 const int r = 4 * s + q;
-                if (r < NX) { real rr = rp[C::oR + r]; acc = fma_(rr, rr, acc); }
+                if (r < NX) { real rr = ro[s]; acc = fma_(rr, rr, acc); }
             }
 #pragma unroll
             for (int m = 0; m < SY; ++m) {
                 const int j = 4 * m + q;
                 if (j < N) {
-                    real z = rp[C::oZ + j];
+                    real z = zo[m];
                     bad |= !(z - z == real(0));
                     if (j >= NX) {
                         real cu = fmax_(z - rp[C::oBU + j - NX], real(0)), cl = fmax_(rp[C::oBL + j - NX] - z, real(0));
