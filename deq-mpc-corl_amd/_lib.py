@@ -13,7 +13,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MI_ALQP_LIB") or os.path.join(_HERE, "csrc", "libmi_alqp.so")   # MI_ALQP_LIB: A/B experiments with a second build of the same ABI
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 
 class AlqpDims(C.Structure):
@@ -96,6 +96,7 @@ _PLAIN = {
     "alqp_workspace_bytes_nonlin": (C.c_size_t, [C.POINTER(AlqpDims), C.c_int]),
     "alqp_ipm_workspace_bytes": (C.c_size_t, [C.POINTER(AlqpDims), C.c_int]),
     "alqp_ipm_set_factor_placement": (C.c_int, [C.c_int]),
+    "alqp_set_quad_stagger": (C.c_int, [C.c_int]),
 }
 
 EXPORTED_SYMBOLS = sorted([f"{n}_{s}" for n in _SIGS for s in ("f32", "f64")] + list(_PLAIN))

@@ -61,6 +61,13 @@ class HipBackend:
     def __init__(self):
         self.lib = _lib.load()
         self._ws = {}  # (device, dtype) -> scratch tensor for the quad variant (grown on demand)
+        if os.environ.get("ALQP_QUAD_STAGGER") is not None:   # -1 auto (default), 0 off, > 0 units of ~1024 clocks
+            self.set_quad_stagger(int(os.environ["ALQP_QUAD_STAGGER"]))
+
+    def set_quad_stagger(self, mode):
+        """Start offset between the four wavefronts of a CU in the quad solve (alqp_set_quad_stagger, include/mi_alqp.h):
+        -1 automatic, 0 off, > 0 explicit. Returns the previous mode. Timing only - results do not depend on it."""
+        return int(self.lib.alqp_set_quad_stagger(int(mode)))
 
     def workspace_bytes(self, B, T, nx, nu, dtype):
         d = _lib.AlqpDims(B, T, nx, nu)

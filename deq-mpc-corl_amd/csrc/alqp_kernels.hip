@@ -37,6 +37,7 @@ struct SolveArgs {
     real *factor;
     const double *skip;  // nullable: *skip != 0 -> the launch does nothing (device-side loop exit)
     real dyn_h;          // nonlinear fused solve: step length of the inlined dynamics model
+    int stagger;         // quad solve: start offset between the four wavefronts of a CU, units of ~1024 clocks (0: none)
 };
 
 template <typename real>
@@ -245,14 +246,19 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     const int b_raw = blockIdx.x * 16 + qi;
     const bool active = b_raw < a.B;
     {
-        // experiment (flags bits 24-31, 0 in production): the wave on SIMD s of its CU starts s * stag * ~1024
-        // clocks late, so that the four waves of a CU are out of phase (memory phase of one under the
-        // arithmetic of the others) instead of marching in lock step
-        const int stag = (a.flags >> 24) & 0xff;
-        if (stag) {
-            const unsigned hw = __builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11));   // HW_REG_HW_ID
+        // Phase shift between the four wavefronts of a CU (one per SIMD, all running the same sweeps): the wave
+        // on SIMD s starts s * stagger * ~1024 clocks late. Started together they march in lock step and queue
+        // on the CU's vector-memory pipeline in their load phases while it idles in their arithmetic phases;
+        // a fifth of a sweep apart, one wave's memory phase runs under the others' panels (+5 % at the headline
+        // size, delay included; shifting whole XCDs instead buys nothing: the contention is inside the CU).
+        // a.stagger is set by the host (quad_stagger(): only when the grid fills the SIMDs and the launch is long
+        // enough to amortise the delay); flags bits 24-31 / 20-23 override it for experiments.
+        int stag = a.stagger;
+        const int mode = (a.flags >> 20) & 0xf;
+        if ((a.flags >> 24) & 0xff) stag = (a.flags >> 24) & 0xff;
+        if (stag > 0) {
+            const unsigned hw = __builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11));   // HW_REG_HW_ID: SIMD id in bits 5:4
             int simd = (hw >> 4) & 3;
-            const int mode = (a.flags >> 20) & 0xf;
             if (mode == 1) simd = simd * 16 + ((hw >> 8) & 0xf);   // all 64 (SIMD, CU-in-array) pairs apart
             if (mode == 2) simd &= 1;                              // two groups per CU
             if (mode == 3) simd = blockIdx.x & 1;                  // two groups of XCDs
@@ -1008,6 +1014,33 @@ static int qpw_query(int nx, int nu) {
 
 static bool dims_ok(const AlqpDims *d) { return d && d->B > 0 && d->T >= 2 && d->nx > 0 && d->nu > 0; }
 
+// ---- start offset between the wavefronts of a CU for the quad solve (SolveArgs::stagger) -------------------
+// g_stagger_mode: -1 auto, 0 off, > 0 explicit units of ~1024 clocks (alqp_set_quad_stagger)
+static int g_stagger_mode = -1;
+static int quad_stagger(int B, int T, int nx, int nu, int newton_steps, bool f64) {
+    if (g_stagger_mode >= 0) return g_stagger_mode;
+    static int n_simd = 0;
+    if (n_simd == 0) {
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) != hipSuccess ||
+            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+            cus = 256;
+        n_simd = 4 * cus;
+    }
+    const long waves = (B + 15) / 16;
+    if (4 * waves < 3 * (long)n_simd || newton_steps < 1) return 0;   // SIMDs not filled: nothing to de-phase
+    // clocks per stage and sweep, fitted on the compiled sizes ((13,4): 26 k, (8,2): 12 k, (6,2): 7 k)
+    const int n = nx + nu;
+    double period = 2000.0 * n - 8000.0;
+    if (period < 3000.0) period = 3000.0;
+    if (f64) period *= 1.4;   // fp64 sweeps take 2.4x as long; measured: 140 units beat 100 at (13,4), T = 20
+    // a fifth of a sweep between neighbouring SIMDs (measured optimum at (13,4), T = 20: 100-125 units), but the
+    // last wave's delay (3 offsets) stays below ~6 % of the launch
+    double frac = 0.04 * newton_steps;
+    if (frac > 0.2) frac = 0.2;
+    return (int)(frac * T * period / 1024.0 + 0.5);
+}
+
 template <typename real>
 int solve_lin_impl(const AlqpDims *dims, const AlqpParams *prm, const void *Qd, const void *q,
                    const void *F, const void *c, const void *x0, const void *u_lo, const void *u_hi,
@@ -1028,6 +1061,7 @@ int solve_lin_impl(const AlqpDims *dims, const AlqpParams *prm, const void *Qd, 
     a.z = (real *)z; a.lam = (real *)lam; a.rho = (real *)rho; a.phi = (real *)phi;
     a.rnorm2 = (real *)rnorm2; a.info = info; a.status = status; a.factor = (real *)factor_out;
     a.skip = prm->skip_flag;
+    a.stagger = quad_stagger(dims->B, dims->T, dims->nx, dims->nu, prm->al_iter * prm->max_newton, sizeof(real) == 8);
     TraceArgs<real> tr = {};
     if (trace) {
         tr.g = (real *)trace->g; tr.d = (real *)trace->d; tr.phi = (real *)trace->phi;
@@ -1445,7 +1479,13 @@ __global__ void k_exit_test(const double *sumsq, double *ctl, int mode, double t
 #if ALQP_BUILD_MAIN
 extern "C" {
 
-int alqp_abi_version(void) { return 6; }
+int alqp_abi_version(void) { return 7; }
+
+int alqp_set_quad_stagger(int mode) {
+    const int prev = alqp::g_stagger_mode;
+    alqp::g_stagger_mode = mode < 0 ? -1 : mode;
+    return prev;
+}
 
 int alqp_dyn_pendulum1l_f32(long K, const void *x, const void *u, double h, const void *h_pt, void *xnext, void *F, void *stream) {
     return alqp::dyn_pendulum1l_impl<float>(K, x, u, h, h_pt, xnext, F, stream);

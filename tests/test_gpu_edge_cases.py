@@ -304,3 +304,32 @@ def test_long_horizon_beyond_team_lds_runs_on_quad_at_small_batch():
     o = orc.solve_lin("f64", c(p.Qd), c(p.q), c(p.F), c(p.c), c(p.x0), c(p.u_lo), c(p.u_hi), c(p.z0), al_iter=1,
                       max_newton=2, exit_mode="fixed")
     assert np.abs(c(z) - o["z"]).max() < 1e-8
+
+
+@pytest.mark.gpu
+def test_quad_stagger_changes_timing_only():
+    """alqp_set_quad_stagger: the start offset between a CU's wavefronts must not change a single bit of the
+    results (B = 16384 fills the SIMDs, so the automatic rule is active)."""
+    from deq_mpc_corl_amd.backend import default_backend
+    from deq_mpc_corl_amd.problems import synthetic_problem
+    be = default_backend()
+    dev = "cuda:0"
+    B, T, nx, nu = 16384, 20, 13, 4
+    p = synthetic_problem(B, T, nx, nu, seed=5, dtype=torch.float32)
+    mv = lambda t: t.to(dev).contiguous()
+    outs = []
+    prev = be.set_quad_stagger(-1)
+    try:
+        for mode in (0, -1, 37):
+            be.set_quad_stagger(mode)
+            z, lam = mv(p.z0).clone(), torch.zeros(B, T * nx + 2 * T * nu, device=dev)
+            rho, phi = torch.ones(B, device=dev), torch.zeros(B, device=dev)
+            be.solve_lin((B, T, nx, nu), mv(p.Qd), mv(p.q), mv(p.F), mv(p.c), mv(p.x0), mv(p.u_lo), mv(p.u_hi), 0, 0,
+                         z, lam, rho, phi, al_iter=2, max_newton=4, variant="quad")
+            torch.cuda.synchronize()
+            outs.append((z.cpu(), lam.cpu(), rho.cpu(), phi.cpu()))
+    finally:
+        be.set_quad_stagger(prev)
+    for o in outs[1:]:
+        for a, b in zip(outs[0], o):
+            assert torch.equal(a, b)
