@@ -196,10 +196,11 @@ struct QCfg {
     static constexpr int oS = oR + 4 * SW;         // s_t = (J d)_eq
     static constexpr int oZ = oS + 4 * SW;         // z_t
     static constexpr int oLE = oZ + 4 * SY;        // lam, equality row block t
-    static constexpr int oLU = oLE + 4 * SW;       // lam, bound rows of stage t: [upper NU | lower NU]
-    static constexpr int oBU = oLU + p4(2 * NU);   // u_upper(t)
-    static constexpr int oBL = oBU + p4(NU);       // u_lower(t)
-    static constexpr int oQ = oBL + p4(NU);        // diag Q_t
+    // the bound rows of stage t, lane-major like the vectors: words 4q..4q+3 = (lam_upper, lam_lower, u_upper,
+    // u_lower) of the ONE control lane q owns (element NX + ju with (NX + ju) % 4 == q; zeros when it owns none)
+    static_assert(NU <= 4, "the u-slot layout holds one control per lane");
+    static constexpr int oUS = oLE + 4 * SW;
+    static constexpr int oQ = oUS + 16;            // diag Q_t
     static constexpr int oq = oQ + 4 * SY;         // q_t
     static constexpr int oC = oq + 4 * SY;         // c_t
     static constexpr int RECW = (oC + 4 * SW + 31) & ~31;  // whole 128-byte lines (fp32)
@@ -314,6 +315,24 @@ struct Quad {
             if (4 * m + 3 < LEN || 4 * m + q < LEN) dst[4 * m + q] = v[m];
     }
 
+    // ---- bound rows (QCfg::oUS): the control this lane owns is ju = (q - NX) mod 4, if that is < NU
+    __device__ __forceinline__ int own_ju() const { return (q - NX) & 3; }
+    __device__ __forceinline__ void ld_own_us(const real *rp, real &lu, real &ll, real &bu, real &bl) const {
+        gld4(rp + C::oUS + 4 * q, lu, ll, bu, bl);
+    }
+    __device__ __forceinline__ void ld_rep_us(const real *rp, real (&lu)[NU], real (&ll)[NU], real (&bu)[NU], real (&bl)[NU]) const {
+        real w[16];
+        gload<16>(rp + C::oUS, w);
+#pragma unroll
+        for (int ju = 0; ju < NU; ++ju) {
+            const int ql = (NX + ju) & 3;
+            lu[ju] = w[4 * ql];
+            ll[ju] = w[4 * ql + 1];
+            bu[ju] = w[4 * ql + 2];
+            bl[ju] = w[4 * ql + 3];
+        }
+    }
+
     // F_t rows of this lane: row 4s+q (zeros for rows >= NX). Loads are unconditional (row
     // index clamped, result masked) so that all of a stage's loads go out in one batch:
     // a load inside a divergent branch cannot be hoisted and costs its own round trip.
@@ -366,9 +385,13 @@ struct Quad {
                 st_own_n(rp + C::oq, vn);
                 ld_own_ext<NX>(glam + t * NX, vx);
                 st_own_x(rp + C::oLE, vx);
-                copy_slice<2 * NU>(glam + T * NX + t * 2 * NU, rp + C::oLU);
-                copy_slice<NU>(guhi + t * st_u, rp + C::oBU);
-                copy_slice<NU>(gulo + t * st_u, rp + C::oBL);
+                {
+                    const int ju = own_ju(), jc = ju < NU ? ju : 0;
+                    const real *lb = glam + T * NX + t * 2 * NU;
+                    const real a0 = lb[jc], a1 = lb[NU + jc], a2 = guhi[t * st_u + jc], a3 = gulo[t * st_u + jc];
+                    const bool has = ju < NU;
+                    gst4(rp + C::oUS + 4 * q, has ? a0 : real(0), has ? a1 : real(0), has ? a2 : real(0), has ? a3 : real(0));
+                }
                 if (dyn && have_c) ld_own_ext<NX>(gc + t * NX, vx);
                 else {
 #pragma unroll
@@ -409,7 +432,15 @@ struct Quad {
             st_own_ext<N>(gz + t * N, vn);
             ld_own_x(rp + C::oLE, vx);
             st_own_ext<NX>(glam + t * NX, vx);
-            copy_slice<2 * NU>(rp + C::oLU, glam + T * NX + t * 2 * NU);
+            {
+                real lu, ll, bu, bl;
+                ld_own_us(rp, lu, ll, bu, bl);
+                const int ju = own_ju();
+                if (ju < NU) {
+                    glam[T * NX + t * 2 * NU + ju] = lu;
+                    glam[T * NX + t * 2 * NU + NU + ju] = ll;
+                }
+            }
         }
     }
 
@@ -517,10 +548,7 @@ struct Quad {
             ld_repx_of_n(rn + C::oZ, zn);
             ld_repx_of_n(rn + C::oY, dn);
             ld_rep_x(rp + C::oLE, le);
-            gload<NU>(rp + C::oLU, lu);
-            gload<NU>(rp + C::oLU + NU, ll);
-            gload<NU>(rp + C::oBU, bu);
-            gload<NU>(rp + C::oBL, bl);
+            ld_rep_us(rp, lu, ll, bu, bl);
             real alpha = a0;
 #pragma unroll
             for (int i = 0; i < 5; ++i) {
@@ -631,10 +659,7 @@ struct Quad {
                 ld_own_x(rp + C::oC, cs);
                 ld_ownx_of_n(rn + C::oZ, zn);
                 ld_own_x(rp + C::oLE, lm);
-                gload<NU>(rp + C::oLU, lu);
-                gload<NU>(rp + C::oLU + NU, ll);
-                gload<NU>(rp + C::oBU, bu);
-                gload<NU>(rp + C::oBL, bl);
+                ld_rep_us(rp, lu, ll, bu, bl);
                 if (pending) {  // wave-uniform: z_t += alpha d_t, z_{t+1}[x] += alpha d_{t+1}[x]
                     real dt[N], dn[SW];
                     ld_rep_n(rp + C::oY, dt);
@@ -863,22 +888,13 @@ struct Quad {
             for (int j = 0; j < N; ++j) Y[j] = qbv(yo[j >> 2], j);
             WT W = wpanel();
             load_F_rows(dyn ? t : (T > 1 ? T - 2 : 0), W);  // same batch as the record loads
-            real zz[SY], QQ[SY], qq[SY], lu[SY], ll[SY], bu[SY], bl[SY], rv[SW], lv[SW];
+            real zz[SY], QQ[SY], qq[SY], rv[SW], lv[SW];
+            real lu = 0, ll = 0, bu = 0, bl = 0;
             if constexpr (LS) {
                 ld_own_n(rp + C::oZ, zz);
                 ld_own_n(rp + C::oQ, QQ);
                 ld_own_n(rp + C::oq, qq);
-#pragma unroll
-                for (int m = 0; m < SY; ++m) {
-                    const int j = 4 * m + q, jc = (4 * m + 3 < N) ? j : (j < N ? j : N - 1);
-                    if (m >= MU0) {
-                        const int ju = jc >= NX ? jc - NX : 0;
-                        lu[m] = rp[C::oLU + ju];
-                        ll[m] = rp[C::oLU + NU + ju];
-                        bu[m] = rp[C::oBU + ju];
-                        bl[m] = rp[C::oBL + ju];
-                    }
-                }
+                ld_own_us(rp, lu, ll, bu, bl);
                 ld_own_x(rp + C::oR, rv);
                 ld_own_x(rp + C::oLE, lv);
             }
@@ -937,6 +953,7 @@ struct Quad {
                 if (active) st_own_x(rp + C::oS, sv);
             }
             if constexpr (LS) {
+                real zu = 0, du = 0;   // the control this lane owns (at most one: NU <= 4)
 #pragma unroll
                 for (int m = 0; m < SY; ++m) {
                     const int j = 4 * m + q;
@@ -949,16 +966,21 @@ struct Quad {
                     c1 = fma_(fma_(Qv, z, qv), d, c1);
                     c2 = fma_(real(0.5) * Qv * d, d, c2);
                     if (m >= MU0) {
-                        const real isu = (j >= NX && j < N) ? real(1) : real(0);
-                        real alpha = 1;
+                        const bool mine = j >= NX && j < N;
+                        zu = mine ? z : zu;
+                        du = mine ? d : du;
+                    }
+                }
+                {
+                    const real isu = own_ju() < NU ? real(1) : real(0);
+                    real alpha = 1;
 #pragma unroll
-                        for (int k = 0; k < 20; ++k) {
-                            real zk = fma_(alpha, d, z);
-                            real vu = zk - bu[m], vl = bl[m] - zk;
-                            real cu = fmax_(vu, real(0)), cl = fmax_(vl, real(0));
-                            acc[k] = fma_(isu, fma_(lu[m], vu, ll[m] * vl) + real(0.5) * rho * fma_(cu, cu, cl * cl), acc[k]);
-                            alpha *= real(0.5);
-                        }
+                    for (int k = 0; k < 20; ++k) {
+                        real zk = fma_(alpha, du, zu);
+                        real vu = zk - bu, vl = bl - zk;
+                        real cu = fmax_(vu, real(0)), cl = fmax_(vl, real(0));
+                        acc[k] = fma_(isu, fma_(lu, vu, ll * vl) + real(0.5) * rho * fma_(cu, cu, cl * cl), acc[k]);
+                        alpha *= real(0.5);
                     }
                 }
                 if (dyn) {
@@ -1092,25 +1114,16 @@ struct Quad {
             const real *rp = recp(t);
             real zz[SY], dd[SY], QQ[SY], qq[SY];
             real rv[SW], sv[SW], lv[SW];
-            real lu[SY], ll[SY], bu[SY], bl[SY];
+            real lu, ll, bu, bl;
             ld_own_n(rp + C::oZ, zz);
             ld_own_n(rp + C::oY, dd);
             ld_own_n(rp + C::oQ, QQ);
             ld_own_n(rp + C::oq, qq);
-#pragma unroll
-            for (int m = 0; m < SY; ++m) {
-                const int j = 4 * m + q, jc = (4 * m + 3 < N) ? j : (j < N ? j : N - 1);
-                if (m >= MU0) {
-                    const int ju = jc >= NX ? jc - NX : 0;
-                    lu[m] = rp[C::oLU + ju];
-                    ll[m] = rp[C::oLU + NU + ju];
-                    bu[m] = rp[C::oBU + ju];
-                    bl[m] = rp[C::oBL + ju];
-                }
-            }
+            ld_own_us(rp, lu, ll, bu, bl);
             ld_own_x(rp + C::oR, rv);
             ld_own_x(rp + C::oS, sv);
             ld_own_x(rp + C::oLE, lv);
+            real zu = 0, du = 0;   // the control this lane owns (at most one: NU <= 4)
 #pragma unroll
             for (int m = 0; m < SY; ++m) {
                 const int j = 4 * m + q;
@@ -1120,16 +1133,21 @@ struct Quad {
                 c1 = fma_(fma_(Qv, z, qv), d, c1);
                 c2 = fma_(real(0.5) * Qv * d, d, c2);
                 if (m >= MU0) {
-                    const real isu = (j >= NX && j < N) ? real(1) : real(0);
-                    real alpha = 1;
+                    const bool mine = j >= NX && j < N;
+                    zu = mine ? z : zu;
+                    du = mine ? d : du;
+                }
+            }
+            {
+                const real isu = own_ju() < NU ? real(1) : real(0);
+                real alpha = 1;
 #pragma unroll
-                    for (int k = 0; k < K; ++k) {
-                        real zk = fma_(alpha, d, z);
-                        real vu = zk - bu[m], vl = bl[m] - zk;
-                        real cu = fmax_(vu, real(0)), cl = fmax_(vl, real(0));
-                        acc[k] = fma_(isu, fma_(lu[m], vu, ll[m] * vl) + real(0.5) * rho * fma_(cu, cu, cl * cl), acc[k]);
-                        alpha *= real(0.5);
-                    }
+                for (int k = 0; k < K; ++k) {
+                    real zk = fma_(alpha, du, zu);
+                    real vu = zk - bu, vl = bl - zk;
+                    real cu = fmax_(vu, real(0)), cl = fmax_(vl, real(0));
+                    acc[k] = fma_(isu, fma_(lu, vu, ll * vl) + real(0.5) * rho * fma_(cu, cu, cl * cl), acc[k]);
+                    alpha *= real(0.5);
                 }
             }
 #pragma unroll
@@ -1173,22 +1191,12 @@ struct Quad {
             real *rp = recp(t);
             real zz[SY], dd[SY], QQ[SY], qq[SY];
             real rv[SW], sv[SW], lv[SW];
-            real lu[SY], ll[SY], bu[SY], bl[SY];
+            real lu, ll, bu, bl;
             ld_own_n(rp + C::oZ, zz);
             ld_own_n(rp + C::oY, dd);
             ld_own_n(rp + C::oQ, QQ);
             ld_own_n(rp + C::oq, qq);
-#pragma unroll
-            for (int m = 0; m < SY; ++m) {
-                const int j = 4 * m + q, jc = (4 * m + 3 < N) ? j : (j < N ? j : N - 1);
-                if (m >= MU0) {
-                    const int ju = jc >= NX ? jc - NX : 0;
-                    lu[m] = rp[C::oLU + ju];
-                    ll[m] = rp[C::oLU + NU + ju];
-                    bu[m] = rp[C::oBU + ju];
-                    bl[m] = rp[C::oBL + ju];
-                }
-            }
+            ld_own_us(rp, lu, ll, bu, bl);
             ld_own_x(rp + C::oR, rv);
             ld_own_x(rp + C::oS, sv);
             ld_own_x(rp + C::oLE, lv);
@@ -1221,6 +1229,7 @@ struct Quad {
                     }
                 }
             }
+            real zu = 0;   // the control this lane owns (at most one: NU <= 4)
 #pragma unroll
             for (int m = 0; m < SY; ++m) {
                 const int j = 4 * m + q;
@@ -1234,31 +1243,29 @@ struct Quad {
                     if (write_out) gz[t * N + j] = z;
                 }
                 c0 = fma_(fma_(real(0.5) * Qv, z, qv), z, c0);
-                if (m >= MU0) {
-                    const bool isub = j >= NX && j < N;
-                    const real isu = isub ? real(1) : real(0);
-                    const int ju = isub ? j - NX : 0;
-                    const real vu = z - bu[m], vl = bl[m] - z;
-                    real lun = lu[m], lln = ll[m];
-                    if (dual) {
-                        const real a = fma_(rho, vu, lu[m]), c = fma_(rho, vl, ll[m]);
-                        lun = a < 0 ? real(0) : a;
-                        lln = c < 0 ? real(0) : c;
-                    }
-                    if (isub && active) {
-                        if (dual) {
-                            rp[C::oLU + ju] = lun;
-                            rp[C::oLU + NU + ju] = lln;
-                        }
-                        if (write_out) {
-                            glam[T * NX + t * 2 * NU + ju] = lun;
-                            glam[T * NX + t * 2 * NU + NU + ju] = lln;
-                        }
-                    }
-                    const real cu = fmax_(vu, real(0)), cl = fmax_(vl, real(0));
-                    acc0 = fma_(isu, fma_(lun, vu, lln * vl) + real(0.5) * rho_n * fma_(cu, cu, cl * cl), acc0);
-                    r2 = fma_(isu, fma_(cu, cu, cl * cl), r2);
+                if (m >= MU0) zu = (j >= NX && j < N) ? z : zu;
+            }
+            {
+                const int ju = own_ju();
+                const bool isub = ju < NU;
+                const real isu = isub ? real(1) : real(0);
+                const real vu = zu - bu, vl = bl - zu;
+                real lun = lu, lln = ll;
+                if (dual) {
+                    const real a = fma_(rho, vu, lu), c = fma_(rho, vl, ll);
+                    lun = a < 0 ? real(0) : a;
+                    lln = c < 0 ? real(0) : c;
                 }
+                if (isub && active) {
+                    if (dual) gst4(rp + C::oUS + 4 * q, lun, lln, bu, bl);
+                    if (write_out) {
+                        glam[T * NX + t * 2 * NU + ju] = lun;
+                        glam[T * NX + t * 2 * NU + NU + ju] = lln;
+                    }
+                }
+                const real cu = fmax_(vu, real(0)), cl = fmax_(vl, real(0));
+                acc0 = fma_(isu, fma_(lun, vu, lln * vl) + real(0.5) * rho_n * fma_(cu, cu, cl * cl), acc0);
+                r2 = fma_(isu, fma_(cu, cu, cl * cl), r2);
             }
             if (pend && active) st_own_n(rp + C::oZ, zz);
 #pragma unroll
@@ -1298,8 +1305,10 @@ struct Quad {
         for (int t = 0; t < T; ++t) {
             const real *rp = recp(t);
             real ro[SW], zo[SY];
+            real ulu, ull, ubu, ubl;
             ld_own_x(rp + C::oR, ro);
             ld_own_n(rp + C::oZ, zo);
+            ld_own_us(rp, ulu, ull, ubu, ubl);
 #pragma unroll
             for (int s = 0; s < SW; ++s) {
                 const int r = 4 * s + q;
@@ -1312,7 +1321,7 @@ struct Quad {
                     real z = zo[m];
                     bad |= !(z - z == real(0));
                     if (j >= NX) {
-                        real cu = fmax_(z - rp[C::oBU + j - NX], real(0)), cl = fmax_(rp[C::oBL + j - NX] - z, real(0));
+                        real cu = fmax_(z - ubu, real(0)), cl = fmax_(ubl - z, real(0));
                         acc += fma_(cu, cu, cl * cl);
                     }
                 }

@@ -3,9 +3,8 @@
 # (the shipped library is A; MI_ALQP_LIB selects B, see deq-mpc-corl_amd/_lib.py)
 set -e
 B=$1; shift
-run() { echo "lib=${1:-shipped} stagger=$2 $3" >> gpurun_out/ab.log
-  MI_ALQP_LIB=$1 ALQP_DEBUG_STAGGER=$2 timeout -k 10 120 python bench.py --no-cpu-baseline --no-extras --steps 20 --warmup 5 $3 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'])" >> gpurun_out/ab.log; }
+run() { echo "lib=${1:-shipped} $2" >> gpurun_out/ab.log
+  MI_ALQP_LIB=$1 timeout -k 10 120 python bench.py --no-cpu-baseline --no-extras --steps 20 --warmup 5 $2 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'])" >> gpurun_out/ab.log; }
 for rep in 1 2; do
-  run "" 0 "$*"; run "$B" 0 "$*"; run "" 110 "$*"; run "$B" 110 "$*"
+  run "" "$*"; run "$B" "$*"
 done
-cat gpurun_out/ab.log
