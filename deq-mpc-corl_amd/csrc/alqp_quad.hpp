@@ -597,82 +597,77 @@ struct Quad {
     // merit needs is in registers here): the starting merit of an AL iteration costs no pass of
     // its own and the launch needs no residual pre-pass.
     __device__ __forceinline__ void forward(real *g_out, real alpha, bool pending, real *phi0) {
-        real mrep = 0, mdist = 0;  // merit terms every lane computes alike / per-lane parts (own rows)
+        real mdist = 0;  // merit terms, per-lane parts (own elements and rows; summed over the quad at the end)
         real S[ST], Sy[SW];
-        real vprev[NX], Syrep[NX];
+        // carried from stage to stage, own rows / elements only (row 4s+q of block t-1 pins element 4s+q of x_t):
+        // vpo = lam + rho r of the previous row block, Syo = (W y) of the previous stage
+        real vpo[SW], Syo[SW];
 #pragma unroll
         for (int i = 0; i < ST; ++i) S[i] = 0;
 #pragma unroll
         for (int s = 0; s < SW; ++s) Sy[s] = 0;
         // stage 0: x_0 is pinned by the initial-state rows (eq row block T-1), al_utils.py:274
         {
-            real z0[NX], xi[NX], li[NX], r0[NX];
-            ld_repx_of_n(recp(0) + C::oZ, z0);
-            gload<NX>(gx0, xi);
-            ld_rep_x(recp(T - 1) + C::oLE, li);
+            real z0[SW], xi[SW], li[SW], r0[SW];
+            ld_ownx_of_n(recp(0) + C::oZ, z0);
+            ld_own_ext<NX>(gx0, xi);
+            ld_own_x(recp(T - 1) + C::oLE, li);
             if (pending) {
-                real d0[NX];
-                ld_repx_of_n(recp(0) + C::oY, d0);
+                real d0[SW];
+                ld_ownx_of_n(recp(0) + C::oY, d0);
 #pragma unroll
-                for (int j = 0; j < NX; ++j) z0[j] = fma_(alpha, d0[j], z0[j]);
+                for (int s = 0; s < SW; ++s) z0[s] = fma_(alpha, d0[s], z0[s]);
             }
 #pragma unroll
-            for (int j = 0; j < NX; ++j) {
-                real r = z0[j] - xi[j];
-                vprev[j] = fma_(rho, r, li[j]);
-                if constexpr (C::PHI0_FWD) mrep = fma_(fma_(real(0.5) * rho, r, li[j]), r, mrep);  // initial-state rows
-                Syrep[j] = 0;
-                r0[j] = r;
+            for (int s = 0; s < SW; ++s) {
+                const bool valid = 4 * s + 3 < NX || 4 * s + q < NX;
+                const real r = valid ? z0[s] - xi[s] : real(0);
+                vpo[s] = valid ? fma_(rho, r, li[s]) : real(0);
+                if constexpr (C::PHI0_FWD) mdist += valid ? fma_(fma_(real(0.5) * rho, r, li[s]), r, real(0)) : real(0);  // initial-state rows
+                Syo[s] = 0;
+                r0[s] = r;
             }
-            if (active) {
-                real ro[SW];
-                own_of<NX, SW>(r0, ro);
-                st_own_x(recp(T - 1) + C::oR, ro);
-            }
+            if (active) st_own_x(recp(T - 1) + C::oR, r0);
         }
         for (int t = 0; t < T; ++t) {
             const bool dyn = t < T - 1;
             WT W = wpanel();
-            real Y[N], D[N];
+            real Y[N];
+            real dio[SY];   // diagonal of H_tt, own elements
             real v[SW];
             real zs[SY];
-#pragma unroll
-            for (int m = 0; m < SY; ++m) zs[m] = 0;
             real *rp = recp(t);
-            // ---- loads (one batch) + residual + multiplier estimate
+            // ---- loads (one batch) + residual + multiplier estimate. Everything per-stage is read as OWN
+            // elements (one or two instructions per vector) and z_t is then broadcast inside the quad: loads
+            // that return the same 80 bytes to all four lanes cost four times the L1 return bandwidth, which
+            // is what the CU's four wavefronts queue on.
             {
-                real zt[N], Qt[N], qt[N];
+                real zt[N];
+                real Qo[SY], qo[SY];
                 real cs[SW], zn[SW], lm[SW];
-                real lu[NU], ll[NU], bu[NU], bl[NU];
-                ld_rep_n(rp + C::oZ, zt);
-                real Qo[SY], qo[SY];  // fp64: own elements only, broadcast where used (48 registers less)
-                if constexpr (C::S_AFTER) {
-                    ld_own_n(rp + C::oQ, Qo);
-                    ld_own_n(rp + C::oq, qo);
-                } else {
-                    ld_rep_n(rp + C::oQ, Qt);
-                    ld_rep_n(rp + C::oq, qt);
-                }
+                real lu, ll, bu, bl;
+                ld_own_n(rp + C::oZ, zs);
+                ld_own_n(rp + C::oQ, Qo);
+                ld_own_n(rp + C::oq, qo);
                 const int td = dyn ? t : (T > 1 ? T - 2 : 0);  // valid addresses for the last stage
                 load_F_rows(td, W);
                 const real *rn = recp(td + 1);
                 ld_own_x(rp + C::oC, cs);
                 ld_ownx_of_n(rn + C::oZ, zn);
                 ld_own_x(rp + C::oLE, lm);
-                ld_rep_us(rp, lu, ll, bu, bl);
+                ld_own_us(rp, lu, ll, bu, bl);
                 if (pending) {  // wave-uniform: z_t += alpha d_t, z_{t+1}[x] += alpha d_{t+1}[x]
-                    real dt[N], dn[SW];
-                    ld_rep_n(rp + C::oY, dt);
+                    real dt[SY], dn[SW];
+                    ld_own_n(rp + C::oY, dt);
                     ld_ownx_of_n(rn + C::oY, dn);
 #pragma unroll
-                    for (int k = 0; k < N; ++k) zt[k] = fma_(alpha, dt[k], zt[k]);
+                    for (int m = 0; m < SY; ++m) zs[m] = fma_(alpha, dt[m], zs[m]);   // written back with the stage results
 #pragma unroll
                     for (int s = 0; s < SW; ++s) zn[s] = fma_(alpha, dn[s], zn[s]);
-                    // own elements of the advanced z_t; written with the stage results below (a
-                    // store here would sit between the loads and their counted waits)
-                    own_of<N, SY>(zt, zs);
                 }
                 ALQP_STAMP(0);  // forward: exposed load latency
+#pragma unroll
+                for (int k = 0; k < N; ++k) zt[k] = qbv(zs[k >> 2], k);
                 real rro[SW];
                 if (!dyn) {
 #pragma unroll
@@ -693,35 +688,59 @@ struct Quad {
                     if constexpr (C::PHI0_FWD) mdist += ok ? fma_(fma_(real(0.5) * rho, rr, lm[s]), rr, real(0)) : real(0);
                 }
                 if (dyn && active) st_own_x(rp + C::oR, rro);
-                // ---- gradient (replicated in the 4 lanes) and diagonal of H_tt
+                // ---- gradient and diagonal of H_tt, own elements (k = 4m + q)
+                constexpr int MU0 = NX / 4;  // first element slot that can hold a control
+                real zu = 0;                 // the control this lane owns (at most one: NU <= 4)
+#pragma unroll
+                for (int m = MU0; m < SY; ++m) zu = (4 * m + q >= NX && 4 * m + q < N) ? zs[m] : zu;
+                const real vu = zu - bu, vl = bl - zu;
+                const real au = vu >= 0 ? real(1) : real(0), al = vl >= 0 ? real(1) : real(0);
+                const real cu = fmax_(vu, real(0)), cl = fmax_(vl, real(0));
+                const real gu = fma_(rho, cu, lu) - fma_(rho, cl, ll);   // bound rows' part of the gradient on that control
+                const real du = rho * (au + al);
+                if constexpr (C::PHI0_FWD)
+                    mdist += own_ju() < NU ? fma_(lu, vu, ll * vl) + real(0.5) * rho * fma_(cu, cu, cl * cl) : real(0);
+                real go[SY];   // -(everything but the F'v term and the Schur carry), per own element
+#pragma unroll
+                for (int m = 0; m < SY; ++m) {
+                    const int j = 4 * m + q;
+                    const bool isx = (4 * m + 3 < NX) ? true : (4 * m >= NX ? false : j < NX);
+                    const bool isu = (4 * m + 3 < NX) ? false : (j >= NX && j < N);
+                    real g = fma_(Qo[m], zs[m], qo[m]);
+                    real d = Qo[m];
+                    if constexpr (C::PHI0_FWD) mdist = fma_(fma_(real(0.5) * Qo[m], zs[m], qo[m]), zs[m], mdist);   // padding: 0
+                    g += isx ? vpo[m < SW ? m : 0] : (isu ? gu : real(0));
+                    d += isx ? rho : (isu ? du : real(0));
+                    dio[m] = d;
+                    go[m] = g;
+                }
+                // Y_j = -(g_j) - (W y)_{t-1,j}: broadcast of the own part plus the quad-reduced F'v term
+#pragma unroll
+                for (int m = 0; m < SY; ++m) {
+                    const bool isx = (4 * m + 3 < NX) ? true : (4 * m >= NX ? false : 4 * m + q < NX);
+                    go[m] = -go[m] - (isx ? Syo[m < SW ? m : 0] : real(0));
+                }
+                real fv[N];
 #pragma unroll
                 for (int j = 0; j < N; ++j) {
-                    const real Qj = C::S_AFTER ? qbv(Qo[j >> 2], j) : Qt[j];
-                    const real qj = C::S_AFTER ? qbv(qo[j >> 2], j) : qt[j];
-                    real g = fma_(Qj, zt[j], qj);
-                    real d = Qj;
-                    if constexpr (C::PHI0_FWD) mrep = fma_(fma_(real(0.5) * Qj, zt[j], qj), zt[j], mrep);
-                    if (j < NX) {
-                        g += vprev[j];
-                        d += rho;
-                    } else {
-                        const int ju = j - NX;
-                        real vu = zt[j] - bu[ju], vl = -zt[j] + bl[ju];
-                        real au = vu >= 0 ? real(1) : real(0), al = vl >= 0 ? real(1) : real(0);
-                        d = fma_(rho, au + al, d);
-                        const real cu = fmax_(vu, real(0)), cl = fmax_(vl, real(0));
-                        g += fma_(rho, cu, lu[ju]) - fma_(rho, cl, ll[ju]);
-                        if constexpr (C::PHI0_FWD) mrep += fma_(lu[ju], vu, ll[ju] * vl) + real(0.5) * rho * fma_(cu, cu, cl * cl);
-                    }
+                    real p = 0;
                     if (dyn) {
-                        real p = 0;
 #pragma unroll
                         for (int s = 0; s < SW; ++s) p = fma_(W[s][j], v[s], p);
-                        g -= qsum(p);
+                        p = qsum(p);
                     }
-                    D[j] = d;
-                    Y[j] = -g - ((j < NX) ? Syrep[j] : real(0));
-                    if (g_out && (j & 3) == q) g_out[t * N + j] = g;
+                    fv[j] = p;
+                    Y[j] = qbv(go[j >> 2], j) + p;
+                }
+                if (g_out) {   // trace only: g = -(Y + carry)
+                    real fo[SY];
+                    own_of<N, SY>(fv, fo);
+#pragma unroll
+                    for (int m = 0; m < SY; ++m) {
+                        const bool isx = (4 * m + 3 < NX) ? true : (4 * m >= NX ? false : 4 * m + q < NX);
+                        if (4 * m + 3 < N || 4 * m + q < N)
+                            g_out[t * N + 4 * m + q] = -(go[m] + fo[m]) - (isx ? Syo[m < SW ? m : 0] : real(0));
+                    }
                 }
             }
             // ---- H_tt rows (lower part, trimmed): diag + (1/rho) w_i w_j - Schur
@@ -732,7 +751,7 @@ struct Quad {
             for (int s = 0; s < SH; ++s)
 #pragma unroll
                 for (int c = 0; c < 4; ++c)
-                    if (4 * s + c < N) H[C::hidx(s, 4 * s + c)] = (q == c) ? D[4 * s + c] : real(0);
+                    if (4 * s + c < N) H[C::hidx(s, 4 * s + c)] = (q == c) ? dio[s] : real(0);
             // minus the Schur complement of stage t-1 (its registers are dead afterwards: keeps
             // the F'F phase below within the 256 architectural VGPRs)
             if (t > 0) {
@@ -840,15 +859,15 @@ struct Quad {
                     }
                 }
             }
-            // ---- carry to the next stage: replicated v = lam + rho r and W_t y_t
+            // ---- carry to the next stage (own rows): v = lam + rho r and W_t y_t
 #pragma unroll
-            for (int j = 0; j < NX; ++j) {
-                vprev[j] = qbv(v[j >> 2], j);
-                Syrep[j] = qbv(Sy[j >> 2], j);
+            for (int s = 0; s < SW; ++s) {
+                vpo[s] = v[s];
+                Syo[s] = Sy[s];
             }
             ALQP_STAMP(3);  // forward: stores drained
         }
-        if constexpr (C::PHI0_FWD) { if (phi0) *phi0 = mrep + qsum(mdist); }
+        if constexpr (C::PHI0_FWD) { if (phi0) *phi0 = qsum(mdist); }
     }
 
     // ---- backward sweep ---------------------------------------------------------------

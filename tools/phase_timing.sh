@@ -6,6 +6,6 @@ set -euo pipefail
 cd "$(dirname "$0")/../deq-mpc-corl_amd/csrc"
 mkdir -p build/timing
 DIMS="${1:-X(13, 4)}"
-sed "s/X(2, 1) X(4, 1) X(4, 2) X(6, 1) X(6, 2) X(8, 2) X(10, 3) X(12, 4) X(13, 4) X(14, 4)/$DIMS/" alqp_kernels.hip > build/timing/alqp_kernels_timing.hip
+cp alqp_kernels.hip build/timing/alqp_kernels_timing.hip
 hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -I../../include -I. -mllvm -pragma-unroll-threshold=1000000 \
-  -DALQP_PHASE_TIMING ${EXTRA_FLAGS:-} -shared build/timing/alqp_kernels_timing.hip -o build/libmi_alqp_timing.so
+  -DALQP_PHASE_TIMING "-DALQP_FOR_EACH_DIMS(X)=$DIMS" ${EXTRA_FLAGS:-} -shared build/timing/alqp_kernels_timing.hip alqp_ipm.hip -o build/libmi_alqp_timing.so
