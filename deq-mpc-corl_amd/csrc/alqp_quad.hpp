@@ -179,7 +179,10 @@ struct QCfg {
     // fp32: the starting merit comes out of the first forward sweep; fp64 is short of registers
     // (it would spill 0.7 KB more) and keeps the residual pre-pass + a merit pass
     static constexpr bool PHI0_FWD = sizeof(real) == 4;   // (fp64, tried again with the W panel in LDS: 520 B of scratch come back)
-    static constexpr bool S_AFTER = sizeof(real) == 8;  // fp64: Schur accumulation after the panel (register pressure)
+#ifndef ALQP_S_AFTER_F32
+#define ALQP_S_AFTER_F32 0   // experiment: 1 gives fp32 256 + 256 registers and 144 B of scratch (profiles/r02/experiments)
+#endif
+    static constexpr bool S_AFTER = sizeof(real) == 8 || ALQP_S_AFTER_F32;  // fp64: Schur accumulation after the panel (register pressure)
 #ifndef ALQP_W_LDS_F32
 #define ALQP_W_LDS_F32 0
 #endif
