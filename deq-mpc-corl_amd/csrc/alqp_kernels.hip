@@ -263,6 +263,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
             if (mode == 2) simd &= 1;                              // two groups per CU
             if (mode == 3) simd = blockIdx.x & 1;                  // two groups of XCDs
             if (mode == 4) simd = (simd & 1) ^ (blockIdx.x & 1);   // two groups, mixed over SIMDs and XCDs
+            if (mode == 5) simd = (hw >> 8) & 3;                   // four groups of CUs, a CU's SIMDs together
             for (int i = 0; i < simd * stag; ++i) __builtin_amdgcn_s_sleep(16);
         }
     }
