@@ -394,12 +394,13 @@ class HipBackend:
         return ws, need
 
     def ipm_solve(self, dims, Cd, c, F, f, x0, uhi, ulo, exit_mode="reference", eps=1e-12, not_improved_lim=3,
-                  max_iter=20, ry_fn=None, kkt_eps=1e-7):
+                  max_iter=20, ry_fn=None, kkt_eps=1e-7, process_group=None, sharded=False):
         """pdipm_b_LU.forward (batch_LU.py:29-197) on time-major data: Cd, c [T,B,n]; F [T-1,B,nx,n];
         f [T-1,B,nx]; x0 [B,nx]; uhi, ulo [nu]. ry_fn(z [B,T*n]) -> [B,T*nx]: equality residual of the TRUE
         dynamics (one launch per iteration, PyTorch call in between), or None for A z - b.
         exit_mode "fixed" (and no ry_fn): ONE launch for the whole solve. "reference": the reference's
-        batch-global exit rule, one host read per iteration (the reference syncs there as well)."""
+        batch-global exit rule, one host read per iteration (the reference syncs there as well); with `sharded`
+        the three batch-global quantities are max-reduced over the ranks of `process_group` first."""
         B, T, nx, nu = dims
         n = nx + nu
         dt, dev = c.dtype, c.device
@@ -437,8 +438,12 @@ class HipBackend:
             launch(_lib.ALQP_IPM_RESID, 0, it, ry)
             if exit_mode == "reference":
                 # batch_LU.py:120-151: nNotImproved counts iterations in which NO instance improved
-                any_imp, best_max, mu_min = torch.stack((improved.max().to(torch.float64), out["resid"].max().to(torch.float64),
-                                                         mu.min().to(torch.float64))).tolist()
+                glob = torch.stack((improved.max().to(torch.float64), out["resid"].max().to(torch.float64),
+                                    -mu.min().to(torch.float64)))
+                if sharded:
+                    torch.distributed.all_reduce(glob, op=torch.distributed.ReduceOp.MAX, group=process_group)
+                any_imp, best_max, mu_min = glob.tolist()
+                mu_min = -mu_min
                 n_not_improved = 0 if (it == 0 or any_imp > 0) else n_not_improved + 1
                 if n_not_improved == not_improved_lim or best_max < eps or mu_min > 1e32:
                     done = it

@@ -88,7 +88,7 @@ class _IPQP(torch.autograd.Function):
             out = mpc.backend.ipm_solve((B, T, nx, n - nx), Cd, c.contiguous(), F.contiguous(), f.contiguous(),
                                         x0.contiguous(), mpc._uhi(c), mpc._ulo(c), exit_mode=mpc.exit_mode,
                                         eps=IPM_EPS, not_improved_lim=IPM_NOT_IMPROVED_LIM,
-                                        max_iter=IPM_MAX_ITER, ry_fn=ry_fn)
+                                        max_iter=IPM_MAX_ITER, ry_fn=ry_fn, **mpc._pg_kwargs())
         mpc.last_ipm = {k: out[k] for k in ("iters", "resid", "info") if k in out}
         ctx.mpc = mpc
         ctx.dims = (B, T, nx, n - nx)
@@ -125,7 +125,7 @@ class MPC(Module):
                  n_batch=None, linesearch_decay=0.2, max_linesearch_iter=10, exit_unconverged=True,
                  detach_unconverged=True, backprop=True, slew_rate_penalty=None, prev_ctrl=None,
                  not_improved_lim=5, best_cost_eps=1e-4, solver_type="dense", single_qp_solve=False,
-                 add_goal_constraint=False, x_goal=None, exit_mode="reference", backend=None):
+                 add_goal_constraint=False, x_goal=None, exit_mode="reference", backend=None, process_group=None):
         super().__init__()
         assert (u_lower is None) == (u_upper is None)
         assert max_linesearch_iter > 0
@@ -164,6 +164,10 @@ class MPC(Module):
         self.add_goal_constraint = False
         self.exit_mode = exit_mode
         self._backend = backend
+        # a batch sharded over ranks (one process per GPU): the reference's batch-global decisions - the interior-point
+        # exit rule (batch_LU.py:120-151) and the SQP line search's `.all()` (qp_wrapper.py:440) - are taken over ALL
+        # ranks (one small all-reduce each), so every rank does what the un-sharded reference would
+        self.process_group = process_group
         self.last_ipm = None
         self.last_alpha = None
 
@@ -173,6 +177,21 @@ class MPC(Module):
             from deq_mpc_corl_amd.backend import default_backend
             self._backend = default_backend()
         return self._backend
+
+    def _sharded(self):
+        return self.process_group is not None or (
+            torch.distributed.is_available() and torch.distributed.is_initialized()
+            and getattr(self, "sync_global_exit", False))
+
+    def _pg_kwargs(self):
+        return {"process_group": self.process_group, "sharded": True} if self._sharded() else {}
+
+    def _global_all(self, flags):
+        """`flags.all()` over the whole batch, i.e. over all ranks of a sharded batch."""
+        ok = flags.all().to(torch.int32).reshape(1)
+        if self._sharded():
+            torch.distributed.all_reduce(ok, op=torch.distributed.ReduceOp.MIN, group=self.process_group)
+        return bool(ok.item())
 
     def _bound(self, v, like):
         v = torch.as_tensor(v, dtype=like.dtype, device=like.device)
@@ -330,7 +349,7 @@ class MPC(Module):
             u_new = u + delta_u * alpha
             x_new = self.rollout(x0, u_new, dx)
             cost_new = self.compute_cost(torch.cat((x_new, u_new), dim=2).transpose(0, 1), cost)
-            if bool((cost_new < cost_total).all()):
+            if self._global_all(cost_new < cost_total):
                 break
             mask = (cost_new >= cost_total).to(x0.dtype)[None, :, None]
             alpha = alpha * self.linesearch_decay * mask + (1 - mask) * alpha
