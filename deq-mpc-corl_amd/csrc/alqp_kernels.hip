@@ -446,7 +446,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
 // ---- one Newton direction (nonlinear-caller mode), quad variant: 16 instances per wavefront, the
 //      factor streamed through (and left in) the workspace records, like the fused quad solve. The
 //      caller evaluated dx_jac -> (xnext = f(z), F) in PyTorch (al_utils.py:233-248); the sweeps run on the
-//      affine model x+ = F z + c with c = xnext - F z, whose residual at z is the true one.
+//      linearisation F at z with the true residual z_{t+1}[x] - xnext_t.
 template <typename real, int NX, int NU>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_newton_step_quad(StepArgs<real> a, real *ws) {
     using C = QCfg<real, NX, NU>;
@@ -477,27 +477,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     qd.dyn_h = 0;
     qd.rho = a.rho[b];
     qd.info = 0;
-    qd.stage_in(false, false);
-    // c_t = xnext_t - F_t z_t into the records (own rows 4s+q)
+    // no copy-in: the forward sweep reads the caller's arrays itself and takes r_t = z_{t+1}[x] - xnext_t
     const real *gxn = a.xnext + (size_t)b * (T - 1) * NX;
-    for (int t = 0; t < T - 1; ++t) {
-        typename Quad<real, NX, NU>::WT W = qd.wpanel();
-        real zt[N];
-        qd.load_F_rows(t, W);
-        gload<N>(qd.gz + t * N, zt);
-#pragma unroll
-        for (int s = 0; s < SW; ++s) {
-            const int r = 4 * s + qd.q;
-            if ((4 * s + 3 < NX || r < NX) && active) {
-                real cv = gxn[t * NX + r];
-#pragma unroll
-                for (int k = 0; k < N; ++k) cv = fma_(-W[s][k], zt[k], cv);
-                qd.recp(t)[C::oC + C::px(r)] = cv;
-            }
-        }
-    }
     real *tg = (a.g_out && active) ? a.g_out + (size_t)b * T * N : nullptr;
-    qd.forward(tg, real(0), false, nullptr);
+    qd.template forward<true>(tg, real(0), false, nullptr, gxn);
     real unused[20];
     qd.template backward<false>(unused);
     if (active) {

@@ -599,7 +599,12 @@ struct Quad {
     // With `phi0` the sweep also returns the merit at the z it linearises at (everything the
     // merit needs is in registers here): the starting merit of an AL iteration costs no pass of
     // its own and the launch needs no residual pre-pass.
-    __device__ __forceinline__ void forward(real *g_out, real alpha, bool pending, real *phi0) {
+    // EXT (one Newton direction for a caller-side line search, k_newton_step_quad): no record was filled - the
+    // stage's vectors come straight from the caller's arrays (own elements, one word per instruction) and the
+    // residual is z_{t+1}[x] - xnext_t with the caller's xnext = f(z_t) (gxn); nothing but the factor and y is
+    // written. Saves the copy-in pass, the pass that formed c_t = xnext - F z (a third read of F) and the re-read.
+    template <bool EXT = false>
+    __device__ __forceinline__ void forward(real *g_out, real alpha, bool pending, real *phi0, const real *gxn = nullptr) {
         real mdist = 0;  // merit terms, per-lane parts (own elements and rows; summed over the quad at the end)
         real S[ST], Sy[SW];
         // carried from stage to stage, own rows / elements only (row 4s+q of block t-1 pins element 4s+q of x_t):
@@ -612,9 +617,14 @@ struct Quad {
         // stage 0: x_0 is pinned by the initial-state rows (eq row block T-1), al_utils.py:274
         {
             real z0[SW], xi[SW], li[SW], r0[SW];
-            ld_ownx_of_n(recp(0) + C::oZ, z0);
+            if constexpr (EXT) {
+                ld_own_ext<NX>(gz, z0);
+                ld_own_ext<NX>(glam + (T - 1) * NX, li);
+            } else {
+                ld_ownx_of_n(recp(0) + C::oZ, z0);
+                ld_own_x(recp(T - 1) + C::oLE, li);
+            }
             ld_own_ext<NX>(gx0, xi);
-            ld_own_x(recp(T - 1) + C::oLE, li);
             if (pending) {
                 real d0[SW];
                 ld_ownx_of_n(recp(0) + C::oY, d0);
@@ -630,7 +640,7 @@ struct Quad {
                 Syo[s] = 0;
                 r0[s] = r;
             }
-            if (active) st_own_x(recp(T - 1) + C::oR, r0);
+            if (!EXT && active) st_own_x(recp(T - 1) + C::oR, r0);
         }
         for (int t = 0; t < T; ++t) {
             const bool dyn = t < T - 1;
@@ -649,16 +659,33 @@ struct Quad {
                 real Qo[SY], qo[SY];
                 real cs[SW], zn[SW], lm[SW];
                 real lu, ll, bu, bl;
-                ld_own_n(rp + C::oZ, zs);
-                ld_own_n(rp + C::oQ, Qo);
-                ld_own_n(rp + C::oq, qo);
                 const int td = dyn ? t : (T > 1 ? T - 2 : 0);  // valid addresses for the last stage
-                load_F_rows(td, W);
                 const real *rn = recp(td + 1);
-                ld_own_x(rp + C::oC, cs);
-                ld_ownx_of_n(rn + C::oZ, zn);
-                ld_own_x(rp + C::oLE, lm);
-                ld_own_us(rp, lu, ll, bu, bl);
+                if constexpr (EXT) {
+                    ld_own_ext<N>(gz + t * N, zs);
+                    ld_own_ext<N>(gQd + t * N, Qo);
+                    ld_own_ext<N>(gq + t * N, qo);
+                    load_F_rows(td, W);
+                    ld_own_ext<NX>(gxn + td * NX, cs);          // xnext_t = f(z_t): takes the place of F z + c
+                    ld_own_ext<NX>(gz + (td + 1) * N, zn);
+                    ld_own_ext<NX>(glam + td * NX, lm);
+                    const int ju = own_ju(), jc = ju < NU ? ju : 0;
+                    const real *lb = glam + T * NX + t * 2 * NU;
+                    const bool has = ju < NU;
+                    lu = has ? lb[jc] : real(0);
+                    ll = has ? lb[NU + jc] : real(0);
+                    bu = has ? guhi[t * st_u + jc] : real(0);
+                    bl = has ? gulo[t * st_u + jc] : real(0);
+                } else {
+                    ld_own_n(rp + C::oZ, zs);
+                    ld_own_n(rp + C::oQ, Qo);
+                    ld_own_n(rp + C::oq, qo);
+                    load_F_rows(td, W);
+                    ld_own_x(rp + C::oC, cs);
+                    ld_ownx_of_n(rn + C::oZ, zn);
+                    ld_own_x(rp + C::oLE, lm);
+                    ld_own_us(rp, lu, ll, bu, bl);
+                }
                 if (pending) {  // wave-uniform: z_t += alpha d_t, z_{t+1}[x] += alpha d_{t+1}[x]
                     real dt[SY], dn[SW];
                     ld_own_n(rp + C::oY, dt);
@@ -682,15 +709,17 @@ struct Quad {
                 for (int s = 0; s < SW; ++s) {
                     const int r = 4 * s + q;
                     real xn = cs[s];
+                    if constexpr (!EXT) {
 #pragma unroll
-                    for (int k = 0; k < N; ++k) xn = fma_(W[s][k], zt[k], xn);
+                        for (int k = 0; k < N; ++k) xn = fma_(W[s][k], zt[k], xn);
+                    }
                     const real rr = zn[s] - xn;
                     const bool ok = dyn && r < NX;
                     v[s] = ok ? fma_(rho, rr, lm[s]) : real(0);
                     rro[s] = ok ? rr : real(0);
                     if constexpr (C::PHI0_FWD) mdist += ok ? fma_(fma_(real(0.5) * rho, rr, lm[s]), rr, real(0)) : real(0);
                 }
-                if (dyn && active) st_own_x(rp + C::oR, rro);
+                if (!EXT && dyn && active) st_own_x(rp + C::oR, rro);
                 // ---- gradient and diagonal of H_tt, own elements (k = 4m + q)
                 constexpr int MU0 = NX / 4;  // first element slot that can hold a control
                 real zu = 0;                 // the control this lane owns (at most one: NU <= 4)
