@@ -482,11 +482,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     real *tg = (a.g_out && active) ? a.g_out + (size_t)b * T * N : nullptr;
     qd.template forward<true>(tg, real(0), false, nullptr, gxn);
     real unused[20];
-    qd.template backward<false>(unused);
+    qd.template backward<false>(unused, a.d_out + (size_t)b * T * N);
     if (active) {
-        real *gd = a.d_out + (size_t)b * T * N;
-        for (int t = 0; t < T; ++t)
-            for (int j = qd.q; j < N; j += 4) gd[t * N + j] = qd.recp(t)[C::oY + C::pn(j)];
         if (qd.q == 0 && a.info && qd.info && a.info[b] == 0) a.info[b] = qd.info;
     }
 }

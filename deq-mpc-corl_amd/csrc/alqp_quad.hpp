@@ -906,8 +906,10 @@ struct Quad {
     // LS: also accumulate the merit of the 20 line-search candidates z + 2^-k d while d_t and
     // s_t = (J d)_t are in registers (algebra: merit_candidates below; the sum runs over the
     // stages in sweep order T-1..0). The extra inputs sit in the record next to L and y.
+    // d_ext (one Newton direction for the caller, k_newton_step_quad): d goes straight to the caller's array and
+    // s = (J d)_eq, which only the fused line search reads, is not stored
     template <bool LS>
-    __device__ __forceinline__ void backward(real (&phi)[20]) {
+    __device__ __forceinline__ void backward(real (&phi)[20], real *d_ext = nullptr) {
         constexpr int MU0 = NX / 4;  // first element slot that can hold a control
         real c0 = 0, c1 = 0, c2 = 0;
         real acc[20];
@@ -987,7 +989,8 @@ struct Quad {
             if (active) {
                 real down[SY];
                 own_of<N, SY>(Y, down);
-                st_own_n(rp + C::oY, down);
+                if (d_ext) st_own_ext<N>(d_ext + t * N, down);
+                else st_own_n(rp + C::oY, down);
             }
             real sv[SW];
 #pragma unroll
@@ -1001,7 +1004,7 @@ struct Quad {
                     for (int k = 0; k < N; ++k) p = fma_(W[s][k], Y[k], p);
                     sv[s] = (4 * s + 3 < NX || r < NX) ? dxs[s] - p : real(0);
                 }
-                if (active) st_own_x(rp + C::oS, sv);
+                if (active && !d_ext) st_own_x(rp + C::oS, sv);
             }
             if constexpr (LS) {
                 real zu = 0, du = 0;   // the control this lane owns (at most one: NU <= 4)
@@ -1058,7 +1061,7 @@ struct Quad {
             ALQP_STAMP(5);  // backward: solves + stores
         }
         // initial-state rows: s = d_0[x]
-        if (active) {
+        if (active && !d_ext) {
             real so[SW];
             own_of<NX, SW>(dxn, so);
             st_own_x(recp(T - 1) + C::oS, so);
