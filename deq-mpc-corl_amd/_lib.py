@@ -13,7 +13,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MI_ALQP_LIB") or os.path.join(_HERE, "csrc", "libmi_alqp.so")   # MI_ALQP_LIB: A/B experiments with a second build of the same ABI
 
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 
 class AlqpDims(C.Structure):
@@ -23,7 +23,8 @@ class AlqpDims(C.Structure):
 class AlqpParams(C.Structure):
     _fields_ = [("al_iter", C.c_int), ("max_newton", C.c_int), ("n_ls", C.c_int),
                 ("flags", C.c_int), ("rho_scale", C.c_double), ("variant", C.c_int),
-                ("skip_flag", C.c_void_p)]
+                ("skip_flag", C.c_void_p), ("exit_tol", C.c_double), ("newton_counts", C.c_void_p),
+                ("exit_scratch", C.c_void_p)]
 
 
 class AlqpTrace(C.Structure):
@@ -44,10 +45,12 @@ ALQP_INIT_MERIT = 1
 ALQP_DUAL_UPDATE = 2
 ALQP_SAVE_FACTOR = 4
 ALQP_WS_PRIMED = 8
+ALQP_EXIT_IN_KERNEL = 16
+ALQP_E_COOP = -4
 VARIANT_AUTO, VARIANT_TEAM, VARIANT_QUAD = 0, 1, 2
 
 ERRORS = {-1: "bad argument", -2: "unsupported (nx, nu) or horizon does not fit in LDS",
-          -3: "kernel launch failed"}
+          -3: "kernel launch failed", -4: "grid too large for a cooperative launch"}
 
 _P = C.c_void_p
 _SIGS = {

@@ -51,6 +51,7 @@ class HipBackend:
     """The product backend: thin argument marshalling over the C ABI."""
 
     name = "hip"
+    supports_exit_in_kernel = True   # solve_lin(newton_counts=...): ALQP_EXIT_IN_KERNEL, cooperative launch
     default_variant = "auto"
     # "auto": the quad variant (16 instances per wavefront, factor streamed through HBM) wins once
     # the batch fills the chip; below that the team variant (one instance per lane team, factor in
@@ -101,10 +102,13 @@ class HipBackend:
     def solve_lin(self, dims, Qd, q, F, c, x0, ulo, uhi, sb_u, st_u, z, lam, rho, phi,
                   rnorm2=None, info=None, status=None, factor=None, al_iter=2, max_newton=4,
                   n_ls=20, flags=_lib.ALQP_INIT_MERIT | _lib.ALQP_DUAL_UPDATE, rho_scale=10.0,
-                  trace=None, variant=None, workspace=None, skip=None):
+                  trace=None, variant=None, workspace=None, skip=None, newton_counts=None, exit_tol=1e-3):
         """variant: None/"auto" (quad unless a factor must be saved), "team", "quad".
         workspace: a dedicated scratch tensor for the quad variant (kept by the caller when
-        the factor it holds afterwards is needed for `backward_ws`); default: a cached one."""
+        the factor it holds afterwards is needed for `backward_ws`); default: a cached one.
+        newton_counts (int32 [al_iter], device): with it the reference's batch-global exit test of the Newton loop
+        runs INSIDE the launch (ALQP_EXIT_IN_KERNEL, one cooperative launch); returns False - nothing launched - when
+        the grid cannot be co-resident (the caller then takes the launch-per-step route), True otherwise."""
         B, T, nx, nu = dims
         dt = z.dtype
         sfx = _dt(z)
@@ -127,6 +131,17 @@ class HipBackend:
         self.last_variant = "quad" if vnum == 2 else "team"
         skp = _ptr(skip, "skip", torch.float64, True)
         p = _lib.AlqpParams(al_iter, max_newton, n_ls, flags | _DEBUG_FLAGS, rho_scale, vnum, skp.value if skp is not None else None)
+        if newton_counts is not None:
+            key = ("exit", z.device)
+            scr = self._ws.get(key)
+            if scr is None or scr.numel() < 2 * B + 1:
+                scr = torch.zeros(2 * B + 1, dtype=torch.float64, device=z.device)
+                self._ws[key] = scr
+            scr[:1].zero_()   # the grid barrier's arrival counter
+            p.flags |= _lib.ALQP_EXIT_IN_KERNEL
+            p.exit_tol = float(exit_tol)
+            p.newton_counts = _ptr(newton_counts, "newton_counts", torch.int32).value
+            p.exit_scratch = scr.data_ptr()
         tr = None
         if trace is not None:
             tr = _lib.AlqpTrace(*[
@@ -140,7 +155,10 @@ class HipBackend:
                 _ptr(info, "info", torch.int32, True), _ptr(status, "status", torch.uint8, True),
                 _ptr(factor, "factor", dt, True), C.byref(tr) if tr is not None else None,
                 _ptr(ws, "workspace", dt, True), ws_bytes, _stream())
+        if rc == _lib.ALQP_E_COOP and newton_counts is not None:
+            return False
         _lib.check(rc, "alqp_solve_lin_" + sfx)
+        return True
 
     def solve_nonlin(self, dims, dyn_id, dyn_h, Qd, q, x0, ulo, uhi, sb_u, st_u, z, lam, rho, phi, rnorm2=None,
                      info=None, status=None, al_iter=2, max_newton=4,

@@ -20,6 +20,8 @@
 #define ALQP_QUAD_F32 (ALQP_PART == 0 || ALQP_PART == 2)
 #define ALQP_QUAD_F64 (ALQP_PART == 0 || ALQP_PART == 3)
 
+#include <hip/hip_cooperative_groups.h>
+
 namespace alqp {
 
 // Kernel arguments are kept lean on purpose: every pointer is two SGPRs for the whole
@@ -38,7 +40,43 @@ struct SolveArgs {
     const double *skip;  // nullable: *skip != 0 -> the launch does nothing (device-side loop exit)
     real dyn_h;          // nonlinear fused solve: step length of the inlined dynamics model
     int stagger;         // quad solve: start offset between the four wavefronts of a CU, units of ~1024 clocks (0: none)
+    // ALQP_EXIT_IN_KERNEL (cooperative launch): the reference's batch-global exit test of the Newton loop inside the launch
+    double exit_tol;
+    int *newton_counts;    // [al_iter] executed Newton steps per AL iteration
+    double *exit_scratch;  // arrival counter, then [2][gridDim.x] per-workgroup partial sums (ping-pong)
 };
+
+// sum of one value per workgroup over the whole (cooperatively launched) grid, the same bits in every lane of every
+// workgroup: partials in workgroup order, 64 interleaved chains, xor butterfly. Every workgroup must call it.
+__device__ inline double grid_sum_ordered(double block_val, double *scratch, int &phase) {
+    // scratch: one arrival counter (8 bytes, zeroed by the host before the launch), then [2][gridDim.x] partials (ping-pong).
+    // Only the partials and the counter are shared between workgroups and all of them are touched with agent-scope
+    // atomics, so no cache write-back / invalidate (a full fence) is needed: a workgroup's own records are its own.
+    // Co-residency of the grid is guaranteed by the cooperative launch, so the spin cannot starve anyone.
+    double *p = scratch + 1 + (size_t)(phase & 1) * gridDim.x;
+    unsigned *cnt = reinterpret_cast<unsigned *>(scratch);
+    if (threadIdx.x == 0) {
+        __hip_atomic_store(p + blockIdx.x, block_val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __builtin_amdgcn_s_waitcnt(0);   // the partial has reached the coherence point before the arrival is counted
+        __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned target = (unsigned)(phase + 1) * gridDim.x;
+        while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) __builtin_amdgcn_s_sleep(2);
+    }
+    __builtin_amdgcn_s_barrier();   // one wavefront per workgroup: re-converges the lanes behind lane 0's spin
+    double s = 0;
+    for (unsigned i = threadIdx.x; i < gridDim.x; i += 64) s += __hip_atomic_load(p + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+    for (int off = 32; off; off >>= 1) s += __shfl_xor(s, off, 64);
+    ++phase;
+    return s;
+}
+// one value per lane group (teams / quads: `leader` marks one lane per instance) -> the workgroup's sum, fixed order
+__device__ inline double wave_sum_leaders(double v, bool leader) {
+    double s = leader ? v : 0.0;
+#pragma unroll
+    for (int off = 32; off; off >>= 1) s += __shfl_xor(s, off, 64);
+    return s;
+}
 
 template <typename real>
 struct TraceArgs {
@@ -109,11 +147,19 @@ __global__ __launch_bounds__(64, 2) void k_solve_lin(SolveArgs<real> a, TraceArg
     tm.residual_sweep();
 
     int step_id = 0;
+    const bool ref_exit = (a.flags & ALQP_EXIT_IN_KERNEL) != 0;   // grid-uniform
+    int gphase = 0;
     for (int it = 0; it < a.al_iter; ++it) {
         if (a.flags & ALQP_INIT_MERIT) {
             real p1[1];
             tm.template merit_candidates<1>(p1, true);
             phi_prev = p1[0];
+        }
+        double nrm_old = 0;
+        int n_done = 0;
+        if (ref_exit) {   // ||r+|| over the whole batch at the start of the Newton loop (al_utils.py:486)
+            const real r0 = tm.rplus2();
+            nrm_old = sqrt(grid_sum_ordered(wave_sum_leaders((double)r0, active && li == 0), a.exit_scratch, gphase));
         }
         for (int st = 0; st < a.max_newton; ++st, ++step_id) {
             real *tg = nullptr;
@@ -183,7 +229,15 @@ __global__ __launch_bounds__(64, 2) void k_solve_lin(SolveArgs<real> a, TraceArg
             for (int e = li; e < neq; e += G) tm.req[e] += alpha * tm.seq[e];
             wave_sync();
             phi_prev = best;  // merit <- new_merit even when rejected (al_utils.py:569)
+            if (ref_exit) {   // al_utils.py:551-564, the same test alqp_exit_test takes between launches
+                const real r1 = tm.rplus2();
+                const double nw = sqrt(grid_sum_ordered(wave_sum_leaders((double)r1, active && li == 0), a.exit_scratch, gphase));
+                ++n_done;
+                if (nw < a.exit_tol || fabs(nrm_old - nw) / nw < a.exit_tol) break;
+                nrm_old = nw;
+            }
         }
+        if (ref_exit && a.newton_counts && blockIdx.x == 0 && lane == 0) a.newton_counts[it] = n_done;
         if (a.flags & ALQP_DUAL_UPDATE) {
             if (active) tm.dual_update();  // in-place on global lam: padding teams must not touch it
             tm.rho *= a.rho_scale;
@@ -305,8 +359,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     // the residual pre-pass is only needed when no forward sweep will run before r is used
     if (!(a.flags & ALQP_WS_PRIMED)) {
         if constexpr (NL) qd.stage_in(false, false);
-        else qd.stage_in(a.max_newton == 0 || a.al_iter == 0 || (!C::PHI0_FWD && (a.flags & ALQP_INIT_MERIT)));
+        else qd.stage_in(a.max_newton == 0 || a.al_iter == 0 || (a.flags & ALQP_EXIT_IN_KERNEL) ||
+                         (!C::PHI0_FWD && (a.flags & ALQP_INIT_MERIT)));
     }
+    const bool ref_exit = (a.flags & ALQP_EXIT_IN_KERNEL) != 0;   // grid-uniform
+    int gphase = 0;
 
     int step_id = 0;
     bool pend = false;  // a chosen step not yet applied (the next forward sweep applies it)
@@ -321,7 +378,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
         if (a.flags & ALQP_INIT_MERIT) {
             if (it > 0) {
                 phi_prev = phi_next;
-            } else if (C::PHI0_FWD && a.max_newton > 0) {
+            } else if (C::PHI0_FWD && a.max_newton > 0 && !ref_exit) {
                 phi_from_forward = true;
             } else {
                 if constexpr (NL) qd.template linearize<Dyn>(real(0), false);  // true residuals for the merit
@@ -331,6 +388,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
             }
         }
         pend = false;
+        double nrm_old = 0;
+        int n_done = 0;
+        if (ref_exit) {   // ||r+|| over the whole batch at the start of the Newton loop (al_utils.py:486)
+            int bad0 = 0;
+            const real r0 = it == 0 ? qd.rplus2(bad0) : rn2;   // later iterations: from iter_end() of the previous one
+            nrm_old = sqrt(grid_sum_ordered(wave_sum_leaders((double)r0, active && qd.q == 0), a.exit_scratch, gphase));
+        }
         for (int st = 0; st < a.max_newton; ++st, ++step_id) {
             real *tg = nullptr;
             if constexpr (TRACE) tg = (tr.g && active) ? tr.g + ((size_t)step_id * a.B + b) * T * N : nullptr;
@@ -379,7 +443,20 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
             alpha_pend = alpha;
             QSTAMP(7);  // pick
             phi_prev = best;  // merit <- new_merit even when rejected (al_utils.py:569)
+            if (ref_exit) {
+                // apply the step now (what the end of a one-step launch does), ||r+||^2 at the new iterate, then the
+                // reference's batch-global test (al_utils.py:551-564; alqp_exit_test between launches otherwise)
+                int bad1 = 0;
+                real ph_unused = 0, r1 = 0;
+                qd.template iter_end<Dyn>(alpha_pend, pend, false, (real)a.rho_scale, false, ph_unused, r1, bad1);
+                pend = false;
+                const double nw = sqrt(grid_sum_ordered(wave_sum_leaders((double)r1, active && qd.q == 0), a.exit_scratch, gphase));
+                ++n_done;
+                if (nw < a.exit_tol || fabs(nrm_old - nw) / nw < a.exit_tol) break;
+                nrm_old = nw;
+            }
         }
+        if (ref_exit && a.newton_counts && blockIdx.x == 0 && lane == 0) a.newton_counts[it] = n_done;
         bad = 0;
         qd.template iter_end<Dyn>(alpha_pend, pend, (a.flags & ALQP_DUAL_UPDATE) != 0, (real)a.rho_scale, it + 1 == a.al_iter,
                     phi_next, rn2, bad);
@@ -827,6 +904,26 @@ __global__ __launch_bounds__(64) void k_dual(AuxArgs<real> a) {
 
 constexpr size_t kMaxLds = 160 * 1024;
 
+// A launch whose first argument carries ALQP_EXIT_IN_KERNEL goes out as a COOPERATIVE launch (the kernel then uses
+// grid-wide barriers; the runtime refuses grids that cannot be co-resident: ALQP_E_COOP, the caller falls back to the
+// launch-per-step route); everything else as a plain launch.
+template <typename T>
+inline int flags_of(const T &) { return 0; }
+template <typename real>
+inline int flags_of(const SolveArgs<real> &a) { return a.flags; }
+template <typename Fn, typename A0, typename... Rest>
+int launch_maybe_coop(Fn fn, unsigned grid, size_t lds, hipStream_t stream, A0 a0, Rest... rest) {
+    if (flags_of(a0) & ALQP_EXIT_IN_KERNEL) {
+        void *argv[] = {(void *)&a0, (void *)&rest...};
+        hipError_t e = hipLaunchCooperativeKernel(reinterpret_cast<const void *>(fn), dim3(grid), dim3(64), argv, (unsigned)lds, stream);
+        if (e == hipErrorCooperativeLaunchTooLarge) { (void)hipGetLastError(); return ALQP_E_COOP; }
+        return e == hipSuccess ? 0 : ALQP_E_LAUNCH;
+    }
+    hipLaunchKernelGGL(fn, dim3(grid), dim3(64), lds, stream, a0, rest...);
+    return hipGetLastError() == hipSuccess ? 0 : ALQP_E_LAUNCH;
+}
+
+
 #if ALQP_BUILD_MAIN
 template <typename real, int NX, int NU>
 size_t lds_bytes_for(int T) {
@@ -846,8 +943,7 @@ int launch_team_kernel(Fn fn, int B, int T, hipStream_t stream, Args... args) {
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return ALQP_E_LAUNCH;
     }
-    hipLaunchKernelGGL(fn, dim3(grid), dim3(64), lds, stream, args...);
-    return hipGetLastError() == hipSuccess ? 0 : ALQP_E_LAUNCH;
+    return launch_maybe_coop(fn, grid, lds, stream, args...);
 }
 
 template <typename real>
@@ -878,8 +974,7 @@ int dispatch_step_quad(int nx, int nu, const StepArgs<real> &a, real *ws, hipStr
 template <typename real, int NX, int NU, typename Fn, typename... Args>
 int launch_quad_kernel(Fn fn, int B, hipStream_t stream, Args... args) {
     const unsigned grid = (unsigned)((B + 15) / 16);
-    hipLaunchKernelGGL(fn, dim3(grid), dim3(64), 0, stream, args...);
-    return hipGetLastError() == hipSuccess ? 0 : ALQP_E_LAUNCH;
+    return launch_maybe_coop(fn, grid, 0, stream, args...);
 }
 
 template <typename real>
@@ -1043,6 +1138,10 @@ int solve_lin_impl(const AlqpDims *dims, const AlqpParams *prm, const void *Qd, 
     a.rnorm2 = (real *)rnorm2; a.info = info; a.status = status; a.factor = (real *)factor_out;
     a.skip = prm->skip_flag;
     a.stagger = quad_stagger(dims->B, dims->T, dims->nx, dims->nu, prm->al_iter * prm->max_newton, sizeof(real) == 8);
+    if (prm->flags & ALQP_EXIT_IN_KERNEL) {
+        if (!prm->exit_scratch || trace || prm->skip_flag) return ALQP_E_BADARG;
+        a.exit_tol = prm->exit_tol; a.newton_counts = prm->newton_counts; a.exit_scratch = prm->exit_scratch;
+    }
     TraceArgs<real> tr = {};
     if (trace) {
         tr.g = (real *)trace->g; tr.d = (real *)trace->d; tr.phi = (real *)trace->phi;
@@ -1460,7 +1559,7 @@ __global__ void k_exit_test(const double *sumsq, double *ctl, int mode, double t
 #if ALQP_BUILD_MAIN
 extern "C" {
 
-int alqp_abi_version(void) { return 7; }
+int alqp_abi_version(void) { return 8; }
 
 int alqp_set_quad_stagger(int mode) {
     const int prev = alqp::g_stagger_mode;

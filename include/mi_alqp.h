@@ -65,6 +65,15 @@ typedef struct AlqpObstacles {
                                launch on it (same z, lam, Qd, q, c, bounds as the arrays passed now): skip the
                                copy-in pass. Only for back-to-back launches of one solve, see INTEGRATION.md */
 
+#define ALQP_EXIT_IN_KERNEL 16 /* alqp_solve_lin: the reference's batch-global exit test of the Newton loop
+                               (al_utils.py:486, 551-564: stop when ||r+|| over the WHOLE batch is below exit_tol or moved
+                               by less than exit_tol relative) is taken INSIDE the launch: one cooperative launch does what
+                               a merit launch + up to max_newton one-step launches + alqp_exit_test in between do, with a
+                               grid-wide barrier and an ordered sum per Newton step. Needs exit_scratch; no trace, no
+                               skip_flag. Returns ALQP_E_COOP when the grid cannot be co-resident (the caller then uses
+                               the launch-per-step route). Single-GPU batches only: a batch sharded over ranks needs the
+                               all-reduce between the steps. */
+
 typedef struct AlqpParams {
     int al_iter;      /* AL outer iterations done by this call (AL_mpc.py:290) */
     int max_newton;   /* Newton steps per AL iteration, reference: 4 (al_utils.py:485) */
@@ -77,6 +86,10 @@ typedef struct AlqpParams {
     const double *skip_flag; /* nullable DEVICE pointer: when *skip_flag != 0 at launch time the call
                          does nothing at all (ctl[0] of alqp_exit_test: the batch-global exit of the
                          reference's Newton loop taken on the device, no host round trip) */
+    /* ALQP_EXIT_IN_KERNEL only (ignored otherwise): */
+    double exit_tol;      /* reference: 1e-3 (al_utils.py:552, 560) */
+    int *newton_counts;   /* nullable DEVICE [al_iter]: executed Newton steps per AL iteration */
+    double *exit_scratch; /* DEVICE, at least 2 * B + 1 doubles; the first one zeroed before every call */
 } AlqpParams;
 
 /* optional per-step trace (all nullable, for tests): S = al_iter*max_newton steps */
@@ -92,6 +105,7 @@ typedef struct AlqpTrace {
 #define ALQP_E_BADARG     (-1)
 #define ALQP_E_UNSUPPORTED (-2)  /* (nx,nu) not instantiated or LDS budget exceeded */
 #define ALQP_E_LAUNCH     (-3)
+#define ALQP_E_COOP       (-4)  /* ALQP_EXIT_IN_KERNEL: the grid is too large for a cooperative launch */
 
 /* 1 if (nx,nu) has a compiled kernel instance (the quad variant then runs any horizon). */
 int alqp_supported(const AlqpDims *dims, int is_f64);

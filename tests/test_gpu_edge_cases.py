@@ -333,3 +333,34 @@ def test_quad_stagger_changes_timing_only():
     for o in outs[1:]:
         for a, b in zip(outs[0], o):
             assert torch.equal(a, b)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,dtype", [(200, torch.float64), (4099, torch.float32), (16384, torch.float32)])
+def test_reference_exit_inside_one_cooperative_launch_equals_launch_per_step(B, dtype):
+    """ALQP_EXIT_IN_KERNEL: the batch-global exit test of the Newton loop taken behind a grid-wide barrier inside one
+    launch must reproduce the launch-per-step route (alqp_exit_test between one-step launches): same Newton-step counts,
+    same iterate, multipliers and penalty (team kernels at B = 200, quad kernels above; 4099 is not a multiple of 16)."""
+    from deq_mpc_corl_amd import MPC, AffineDynamics, QuadCost
+    from deq_mpc_corl_amd.problems import synthetic_problem
+    dev = "cuda:0"
+    T, nx, nu = 20, 13, 4
+    p = synthetic_problem(B, T, nx, nu, seed=11, dtype=dtype, device=dev, active=True)
+    cost = QuadCost(torch.diag_embed(p.Qd), p.q, torch.zeros(B, T, dtype=dtype, device=dev))
+    dyn = AffineDynamics(p.F, p.c)
+    res = {}
+    for in_kernel in (True, False):
+        mpc = MPC(nx, nu, T, u_lower=p.u_lo, u_upper=p.u_hi, n_batch=B, dtype=dtype, exit_mode="reference",
+                  exit_in_kernel=in_kernel)
+        mpc.reinitialize(p.x0, None)
+        mpc.al_iter = 3
+        x, u, _ = mpc(p.x0, cost, dyn, dyn.jac, x_init=p.z0[..., :nx].clone(), u_init=p.z0[..., nx:].clone())
+        torch.cuda.synchronize()
+        res[in_kernel] = (list(mpc.last_newton_per_al), x.cpu(), u.cpu(), mpc.lamda_prev.cpu(), mpc.rho_prev.cpu())
+    assert res[True][0] == res[False][0] and len(res[True][0]) == 3
+    assert 1 <= min(res[True][0]) and max(res[True][0]) <= 4
+    # not bit-identical in the team kernels: a launch starts from residuals evaluated afresh at z, the single launch
+    # carries r + alpha s from step to step (as the fixed-mode launch always has)
+    tol = 1e-10 if dtype == torch.float64 else 2e-4
+    for a, b in zip(res[True][1:], res[False][1:]):
+        assert float((a.double() - b.double()).abs().max()) <= tol * max(1.0, float(b.double().abs().max()))
