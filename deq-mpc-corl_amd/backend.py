@@ -132,16 +132,7 @@ class HipBackend:
         skp = _ptr(skip, "skip", torch.float64, True)
         p = _lib.AlqpParams(al_iter, max_newton, n_ls, flags | _DEBUG_FLAGS, rho_scale, vnum, skp.value if skp is not None else None)
         if newton_counts is not None:
-            key = ("exit", z.device)
-            scr = self._ws.get(key)
-            if scr is None or scr.numel() < 2 * B + 1:
-                scr = torch.zeros(2 * B + 1, dtype=torch.float64, device=z.device)
-                self._ws[key] = scr
-            scr[:1].zero_()   # the grid barrier's arrival counter
-            p.flags |= _lib.ALQP_EXIT_IN_KERNEL
-            p.exit_tol = float(exit_tol)
-            p.newton_counts = _ptr(newton_counts, "newton_counts", torch.int32).value
-            p.exit_scratch = scr.data_ptr()
+            self._exit_in_kernel(p, B, z.device, newton_counts, exit_tol)
         tr = None
         if trace is not None:
             tr = _lib.AlqpTrace(*[
@@ -160,9 +151,23 @@ class HipBackend:
         _lib.check(rc, "alqp_solve_lin_" + sfx)
         return True
 
+    def _exit_in_kernel(self, p, B, device, newton_counts, exit_tol):
+        """AlqpParams fields of ALQP_EXIT_IN_KERNEL: the cached scratch (arrival counter + 2 x B partial sums)."""
+        key = ("exit", device)
+        scr = self._ws.get(key)
+        if scr is None or scr.numel() < 2 * B + 1:
+            scr = torch.zeros(2 * B + 1, dtype=torch.float64, device=device)
+            self._ws[key] = scr
+        scr[:1].zero_()   # the grid barrier's arrival counter
+        p.flags |= _lib.ALQP_EXIT_IN_KERNEL
+        p.exit_tol = float(exit_tol)
+        p.newton_counts = _ptr(newton_counts, "newton_counts", torch.int32).value
+        p.exit_scratch = scr.data_ptr()
+
     def solve_nonlin(self, dims, dyn_id, dyn_h, Qd, q, x0, ulo, uhi, sb_u, st_u, z, lam, rho, phi, rnorm2=None,
                      info=None, status=None, al_iter=2, max_newton=4,
-                     flags=_lib.ALQP_INIT_MERIT | _lib.ALQP_DUAL_UPDATE, rho_scale=10.0, skip=None, workspace=None):
+                     flags=_lib.ALQP_INIT_MERIT | _lib.ALQP_DUAL_UPDATE, rho_scale=10.0, skip=None, workspace=None,
+                     newton_counts=None, exit_tol=1e-3):
         """Nonlinear fused solve (alqp_solve_nonlin): the dynamics model `dyn_id` is inlined.
         workspace: a private one (new_workspace_nonlin) when the factor and linearisation it holds
         afterwards are needed by backward_ws; default: a cached one."""
@@ -185,14 +190,19 @@ class HipBackend:
                 self._ws[key] = ws
         skp = _ptr(skip, "skip", torch.float64, True)
         p = _lib.AlqpParams(al_iter, max_newton, 20, flags, rho_scale, 2, skp.value if skp is not None else None)
+        if newton_counts is not None:   # the reference's exit test inside one cooperative launch, see solve_lin
+            self._exit_in_kernel(p, B, z.device, newton_counts, exit_tol)
         fn = getattr(self.lib, "alqp_solve_nonlin_" + sfx)
         rc = fn(C.byref(d), C.byref(p), int(dyn_id), float(dyn_h), _ptr(Qd, "Qd", dt), _ptr(q, "q", dt), _ptr(x0, "x0", dt),
                 _ptr(ulo, "u_lower", dt), _ptr(uhi, "u_upper", dt), sb_u, st_u, _ptr(z, "z", dt), _ptr(lam, "lam", dt),
                 _ptr(rho, "rho", dt), _ptr(phi, "phi", dt), _ptr(rnorm2, "rnorm2", dt, True),
                 _ptr(info, "info", torch.int32, True), _ptr(status, "status", torch.uint8, True),
                 _ptr(ws, "workspace", dt), need, _stream())
+        if rc == _lib.ALQP_E_COOP and newton_counts is not None:
+            return False
         _lib.check(rc, "alqp_solve_nonlin_" + sfx)
         self.last_variant = "quad"
+        return True
 
     def dyn_pendulum1l(self, x, u, h, want_jac=True):
         """pendulum1l provider (alqp_dyn_pendulum1l): x [K,2], u [K,1], h float or [K(,1)] tensor

@@ -1201,6 +1201,10 @@ int solve_nonlin_impl(const AlqpDims *dims, const AlqpParams *prm, int dyn_id, d
     a.rnorm2 = (real *)rnorm2; a.info = info; a.status = status; a.factor = nullptr;
     a.skip = prm->skip_flag;
     a.dyn_h = (real)dyn_h;
+    if (prm->flags & ALQP_EXIT_IN_KERNEL) {
+        if (!prm->exit_scratch || prm->skip_flag) return ALQP_E_BADARG;
+        a.exit_tol = prm->exit_tol; a.newton_counts = prm->newton_counts; a.exit_scratch = prm->exit_scratch;
+    }
     return dispatch_solve_nonlin<real>(dyn_id, dims->nx, dims->nu, a, (real *)workspace, (hipStream_t)stream);
 }
 

@@ -662,6 +662,22 @@ class MPC(Module):
                         and getattr(st.dx, "fused_id", None) is not None and hasattr(be, "solve_nonlin")
                         and (getattr(st.dx, "fused_default", True) or self.prefer_fused)
                         and (getattr(st.dx, "nx", None), getattr(st.dx, "nu", None)) == (nx, nu))
+            if fused_nl and not self._sharded() and getattr(be, "supports_exit_in_kernel", False) and (
+                    self.exit_in_kernel is True or (self.exit_in_kernel == "auto" and -(-B // 16) <= 512)):
+                # launch-bound batch: the whole nonlinear solve with the reference's exit rule in ONE cooperative launch
+                if need_grad and "nlws" not in ws:
+                    ws["nlws"] = be.new_workspace_nonlin(dims, st.z)
+                counts = torch.zeros(self.al_iter, dtype=torch.int32, device=dev)
+                if be.solve_nonlin(dims, st.dx.fused_id, st.dx.dt, Qd, q, st.x0, lo, hi, sb, stt, st.z, st.lam, st.rho,
+                                   ws["phi"], rnorm2=ws["rn2"], info=ws["info"], status=ws["status"],
+                                   al_iter=self.al_iter, max_newton=MAX_NEWTON,
+                                   flags=_abi.ALQP_INIT_MERIT | _abi.ALQP_DUAL_UPDATE, rho_scale=RHO_SCALE,
+                                   workspace=ws.get("nlws"), newton_counts=counts):
+                    npa = list(counts.unbind())
+                    rho_last = st.rho / RHO_SCALE
+                    if need_grad:
+                        F_last = be.nonlin_F_view(ws["nlws"], dims)
+                    num_iters = 0
             for _ in range(num_iters):
                 rho_last = st.rho.clone()
                 if fused_nl:
