@@ -1105,6 +1105,9 @@ static int quad_stagger(int B, int T, int nx, int nu, int newton_steps, bool f64
     }
     const long waves = (B + 15) / 16;
     if (4 * waves < 3 * (long)n_simd || newton_steps < 1) return 0;   // SIMDs not filled: nothing to de-phase
+    // measured per size at B = 16384 (profiles/r02/experiments): (13,4) T=20 +1.7 %, T=50 +1.2 %, (14,4) +1.7 %,
+    // (6,2) +0.8 %, (8,2) -0.3 %, (2,1) at B = 65536 -2.5 %: only the sizes with long stages gain
+    if (nx + nu < 12) return 0;
     // clocks per stage and sweep, fitted on the compiled sizes ((13,4): 26 k, (8,2): 12 k, (6,2): 7 k)
     const int n = nx + nu;
     double period = 2000.0 * n - 8000.0;
