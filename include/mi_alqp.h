@@ -422,7 +422,7 @@ int alqp_abi_version(void);
 /* Quad solve (alqp_solve_lin, variant quad / auto at B >= 4096): start offset between the four wavefronts of a CU.
  * All wavefronts run the same sweeps; started together they queue on the CU's vector-memory pipeline in lock
  * step. mode -1 (default): automatic - a fifth of a sweep between neighbouring SIMDs when the grid fills the
- * SIMDs and the launch holds enough Newton steps to amortise the delay; 0: off; > 0: that many units of
+ * SIMDs, nx + nu >= 12 and the launch holds enough Newton steps to amortise the delay; 0: off; > 0: that many units of
  * ~1024 clocks. Returns the previous mode. Results do not depend on it (it only delays wave starts).
  * No counterpart in the reference (a scheduling control of this library). */
 int alqp_set_quad_stagger(int mode);
