@@ -13,7 +13,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MI_ALQP_LIB") or os.path.join(_HERE, "csrc", "libmi_alqp.so")   # MI_ALQP_LIB: A/B experiments with a second build of the same ABI
 
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 
 class AlqpDims(C.Structure):
@@ -59,6 +59,7 @@ _SIGS = {
                                     C.c_long, C.c_long, _P, _P, _P, _P, _P, _P, _P, _P, C.c_size_t, _P]),
     "alqp_dyn_pendulum1l": (C.c_int, [C.c_long, _P, _P, C.c_double, _P, _P, _P, _P]),
     "alqp_dyn_cartpole1l": (C.c_int, [C.c_long, _P, _P, C.c_double, _P, _P, _P, _P]),
+    "alqp_dyn_cartpole1l_v2": (C.c_int, [C.c_long, _P, _P, C.c_double, _P, _P, _P, _P]),
     "alqp_dyn_cartpole2l": (C.c_int, [C.c_long, _P, _P, C.c_double, _P, _P, _P, _P]),
     "alqp_solve_lin": (C.c_int, [C.POINTER(AlqpDims), C.POINTER(AlqpParams), _P, _P, _P, _P, _P, _P, _P,
                                  C.c_long, C.c_long, _P, _P, _P, _P, _P, _P, _P, _P,

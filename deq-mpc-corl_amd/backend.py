@@ -220,9 +220,10 @@ class HipBackend:
         _lib.check(rc, "alqp_dyn_pendulum1l")
         return xn, F
 
-    def dyn_cartpole1l(self, x, tau, h, want_jac=True):
-        """cartpole1l provider (alqp_dyn_cartpole1l): x [K,4], tau [K,2], h float or per-point tensor
-        -> xnext [K,4], J [K,4,6] (d xnext / d(q, qdot, tau)) or None."""
+    def dyn_cartpole1l(self, x, tau, h, want_jac=True, version=1):
+        """cartpole1l provider (alqp_dyn_cartpole1l; version=2: alqp_dyn_cartpole1l_v2, the cartpole1l_v2 package's
+        constants): x [K,4], tau [K,2], h float or per-point tensor -> xnext [K,4], J [K,4,6] (d xnext / d(q, qdot, tau))
+        or None."""
         K = x.shape[0]
         dt = x.dtype
         xn = torch.empty(K, 4, dtype=dt, device=x.device)
@@ -230,7 +231,7 @@ class HipBackend:
         hpt = h.to(dt).reshape(-1).contiguous() if torch.is_tensor(h) else None
         if hpt is not None and hpt.numel() != K:
             raise ValueError("mi_alqp: h must be a number or one value per point")
-        fn = getattr(self.lib, "alqp_dyn_cartpole1l_" + _dt(x))
+        fn = getattr(self.lib, ("alqp_dyn_cartpole1l_v2_" if version == 2 else "alqp_dyn_cartpole1l_") + _dt(x))
         rc = fn(K, _ptr(x, "x", dt), _ptr(tau, "tau", dt), 0.0 if hpt is not None else float(h), _ptr(hpt, "h", dt, True),
                 _ptr(xn, "xnext", dt), _ptr(J, "J", dt, True), _stream())
         _lib.check(rc, "alqp_dyn_cartpole1l")

@@ -1394,8 +1394,14 @@ int dyn_pendulum1l_impl(long K, const void *x, const void *u, double h, const vo
 }
 
 // ---- dynamics provider: cartpole1l (deqmpc/my_envs/cartpole1l/src/generated_dynamics.c,
-//      generated_derivatives.c). RK4 of M(th) q'' = tau - (sin th th'^2, 0) + (0, 9.81 sin th),
-//      M = [[11, -cos th], [-cos th, 2]], with the six tangents w.r.t. (q, qdot, tau).
+//      generated_derivatives.c). RK4 of M(th) q'' = tau - (mb sin th th'^2, 0) + (0, 9.81 mb sin th),
+//      M = [[ma, -mb cos th], [-mb cos th, md]], with the six tangents w.r.t. (q, qdot, tau).
+//      cartpole1l: (ma, mb, md) = (11, 1, 2); cartpole1l_v2 (my_envs/cartpole1l_v2, same model, lighter cart
+//      and pole): (0.7, 0.1, 0.05) - oracle/dyn_oracle.c, pinned by tests/golden/dyn_cartpole1l{,_v2}.npz.
+template <typename real>
+struct CartPar {
+    real ma, mb, md;
+};
 template <typename real>
 struct Dual6 {
     real v, d[6];
@@ -1425,7 +1431,7 @@ __device__ __forceinline__ Dual6<real> d6mul(Dual6<real> a, Dual6<real> b) {
     return r;
 }
 template <typename real>
-__device__ __forceinline__ void cart_acc(Dual6<real> th, Dual6<real> thd, Dual6<real> t0, Dual6<real> t1,
+__device__ __forceinline__ void cart_acc(CartPar<real> p, Dual6<real> th, Dual6<real> thd, Dual6<real> t0, Dual6<real> t1,
                                          Dual6<real> &xdd, Dual6<real> &thdd) {
     using D = Dual6<real>;
     const real snv = sin(th.v), csv = cos(th.v);
@@ -1437,19 +1443,20 @@ __device__ __forceinline__ void cart_acc(Dual6<real> th, Dual6<real> thd, Dual6<
         sn.d[i] = csv * th.d[i];
         cs.d[i] = -snv * th.d[i];
     }
-    const D r0 = d6axpy(t0, real(-1), d6mul(sn, d6mul(thd, thd)));  // tau0 - sin(th) thd^2
-    const D r1 = d6axpy(t1, real(9.81), sn);                         // tau1 + 9.81 sin(th)
-    const D det = d6axpy(d6c<real>(real(22)), real(-1), d6mul(cs, cs));
+    const D r0 = d6axpy(t0, -p.mb, d6mul(sn, d6mul(thd, thd)));       // tau0 - mb sin(th) thd^2
+    const D r1 = d6axpy(t1, real(9.81) * p.mb, sn);                   // tau1 + 9.81 mb sin(th)
+    const D det = d6axpy(d6c<real>(p.ma * p.md), -p.mb * p.mb, d6mul(cs, cs));
     D idet;
     idet.v = real(1) / det.v;
 #pragma unroll
     for (int i = 0; i < 6; ++i) idet.d[i] = -det.d[i] * idet.v * idet.v;
-    xdd = d6mul(idet, d6axpy(d6mul(cs, r1), real(2), r0));    // M^-1 = [[2, c], [c, 11]] / det
-    thdd = d6mul(idet, d6axpy(d6mul(cs, r0), real(11), r1));
+    const D zero = d6c<real>(real(0));
+    xdd = d6mul(idet, d6axpy(d6axpy(zero, p.mb, d6mul(cs, r1)), p.md, r0));    // M^-1 = [[md, mb c], [mb c, ma]] / det
+    thdd = d6mul(idet, d6axpy(d6axpy(zero, p.mb, d6mul(cs, r0)), p.ma, r1));
 }
 template <typename real>
 __global__ __launch_bounds__(256) void k_dyn_cartpole1l(long K, const real *x, const real *tau, real h, const real *hpt,
-                                                        real *xn, real *J) {
+                                                        real *xn, real *J, CartPar<real> par) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= K) return;
     if (hpt) h = hpt[i];
@@ -1461,13 +1468,13 @@ __global__ __launch_bounds__(256) void k_dyn_cartpole1l(long K, const real *x, c
     px.d[0] = 1; th.d[1] = 1; xd.d[2] = 1; thd.d[3] = 1; t0.d[4] = 1; t1.d[5] = 1;
     const real hh = real(0.5) * h, two = real(2), h6 = h / real(6);
     D k1xd, k1td, k2xd, k2td, k3xd, k3td, k4xd, k4td;
-    cart_acc(th, thd, t0, t1, k1xd, k1td);
+    cart_acc(par, th, thd, t0, t1, k1xd, k1td);
     const D k2x = d6axpy(xd, hh, k1xd), k2t = d6axpy(thd, hh, k1td);
-    cart_acc(d6axpy(th, hh, thd), k2t, t0, t1, k2xd, k2td);
+    cart_acc(par, d6axpy(th, hh, thd), k2t, t0, t1, k2xd, k2td);
     const D k3x = d6axpy(xd, hh, k2xd), k3t = d6axpy(thd, hh, k2td);
-    cart_acc(d6axpy(th, hh, k2t), k3t, t0, t1, k3xd, k3td);
+    cart_acc(par, d6axpy(th, hh, k2t), k3t, t0, t1, k3xd, k3td);
     const D k4x = d6axpy(xd, h, k3xd), k4t = d6axpy(thd, h, k3td);
-    cart_acc(d6axpy(th, h, k3t), k4t, t0, t1, k4xd, k4td);
+    cart_acc(par, d6axpy(th, h, k3t), k4t, t0, t1, k4xd, k4td);
     D o[4];
     o[0] = d6axpy(px, h6, d6axpy(d6axpy(xd, two, k2x), real(1), d6axpy(k4x, two, k3x)));
     o[1] = d6axpy(th, h6, d6axpy(d6axpy(thd, two, k2t), real(1), d6axpy(k4t, two, k3t)));
@@ -1488,11 +1495,13 @@ __global__ __launch_bounds__(256) void k_dyn_cartpole1l(long K, const real *x, c
 }
 
 template <typename real>
-int dyn_cartpole1l_impl(long K, const void *x, const void *tau, double h, const void *hpt, void *xn, void *J, void *stream) {
+int dyn_cartpole1l_impl(long K, const void *x, const void *tau, double h, const void *hpt, void *xn, void *J, void *stream,
+                        int version = 1) {
     if (K < 0 || !x || !tau || (!xn && !J)) return ALQP_E_BADARG;
     if (K == 0) return 0;
+    const CartPar<real> par = version == 2 ? CartPar<real>{real(0.7), real(0.1), real(0.05)} : CartPar<real>{real(11), real(1), real(2)};
     hipLaunchKernelGGL(k_dyn_cartpole1l<real>, dim3((unsigned)((K + 255) / 256)), dim3(256), 0, (hipStream_t)stream, K,
-                       (const real *)x, (const real *)tau, (real)h, (const real *)hpt, (real *)xn, (real *)J);
+                       (const real *)x, (const real *)tau, (real)h, (const real *)hpt, (real *)xn, (real *)J, par);
     return hipGetLastError() == hipSuccess ? 0 : ALQP_E_LAUNCH;
 }
 
@@ -1566,7 +1575,7 @@ __global__ void k_exit_test(const double *sumsq, double *ctl, int mode, double t
 #if ALQP_BUILD_MAIN
 extern "C" {
 
-int alqp_abi_version(void) { return 8; }
+int alqp_abi_version(void) { return 9; }
 
 int alqp_set_quad_stagger(int mode) {
     const int prev = alqp::g_stagger_mode;
@@ -1586,6 +1595,12 @@ int alqp_dyn_cartpole1l_f32(long K, const void *x, const void *tau, double h, co
 }
 int alqp_dyn_cartpole1l_f64(long K, const void *x, const void *tau, double h, const void *h_pt, void *xnext, void *J, void *stream) {
     return alqp::dyn_cartpole1l_impl<double>(K, x, tau, h, h_pt, xnext, J, stream);
+}
+int alqp_dyn_cartpole1l_v2_f32(long K, const void *x, const void *tau, double h, const void *h_pt, void *xnext, void *J, void *stream) {
+    return alqp::dyn_cartpole1l_impl<float>(K, x, tau, h, h_pt, xnext, J, stream, 2);
+}
+int alqp_dyn_cartpole1l_v2_f64(long K, const void *x, const void *tau, double h, const void *h_pt, void *xnext, void *J, void *stream) {
+    return alqp::dyn_cartpole1l_impl<double>(K, x, tau, h, h_pt, xnext, J, stream, 2);
 }
 
 int alqp_dyn_cartpole2l_f32(long K, const void *x, const void *tau, double h, const void *h_pt, void *xnext, void *J, void *stream) {

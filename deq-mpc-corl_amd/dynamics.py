@@ -98,6 +98,37 @@ class cartpole1l:
         return [J[:, 2 * i:2 * i + 2, 2 * j:2 * j + 2].contiguous() for i in (0, 1) for j in (0, 1, 2)]
 
 
+class Cartpole1lV2Dynamics(Cartpole1lDynamics):
+    """The reference's second one-link cartpole package (`my_envs/cartpole1l_v2`: cart 0.5 kg, pole 0.2 kg at 0.5 m;
+    shipped but not imported by `my_envs/cartpole.py:35`). Same state and action layout; provider kernels only - the
+    model is not compiled into the nonlinear fused solve, so an MPC on it runs in nonlinear-caller mode."""
+    fused_id = None
+
+    def __call__(self, x, u):
+        xn, _ = self._be().dyn_cartpole1l(x.contiguous(), self._tau(u), self.dt, want_jac=False, version=2)
+        return xn
+
+    def jac(self, x, u):
+        xn, J = self._be().dyn_cartpole1l(x.contiguous(), self._tau(u), self.dt, want_jac=True, version=2)
+        return xn, (J[..., :4], J[..., 4:5])
+
+
+class cartpole1l_v2:
+    """Module-shaped twin of the reference's compiled `cartpole1l_v2` package (conventions of `cartpole1l`)."""
+
+    @staticmethod
+    def dynamics(q_in, qdot_in, tau_in, h_in):
+        be = default_backend()
+        xn, _ = be.dyn_cartpole1l(torch.cat((q_in, qdot_in), 1).contiguous(), tau_in.contiguous(), h_in, want_jac=False, version=2)
+        return [xn[:, :2].contiguous(), xn[:, 2:].contiguous()]
+
+    @staticmethod
+    def derivatives(q_in, qdot_in, tau_in, h_in):
+        be = default_backend()
+        _, J = be.dyn_cartpole1l(torch.cat((q_in, qdot_in), 1).contiguous(), tau_in.contiguous(), h_in, want_jac=True, version=2)
+        return [J[:, 2 * i:2 * i + 2, 2 * j:2 * j + 2].contiguous() for i in (0, 1) for j in (0, 1, 2)]
+
+
 class Cartpole2lDynamics:
     """Two-link cartpole (`CartpoleDynamics(nx=6)`, my_envs/cartpole.py:30-32): x = (cart position,
     th1, th2 relative to link 1, their rates), both angles 0 = upright; tau = (u, 0, 0)."""

@@ -289,6 +289,11 @@ int alqp_dyn_pendulum1l_f64(long K, const void *x, const void *u, double h, cons
  */
 int alqp_dyn_cartpole1l_f32(long K, const void *x, const void *tau, double h, const void *h_pt, void *xnext, void *J, void *stream);
 int alqp_dyn_cartpole1l_f64(long K, const void *x, const void *tau, double h, const void *h_pt, void *xnext, void *J, void *stream);
+/* cartpole1l_v2 (deqmpc/my_envs/cartpole1l_v2/src: a package the reference ships but does not import,
+ * my_envs/cartpole.py:35): the same model with M = [[0.7, -0.1 cos th], [-0.1 cos th, 0.05]], Coriolis 0.1 sin(th) th'^2,
+ * gravity 0.981 sin(th); same arrays as alqp_dyn_cartpole1l. */
+int alqp_dyn_cartpole1l_v2_f32(long K, const void *x, const void *tau, double h, const void *h_pt, void *xnext, void *J, void *stream);
+int alqp_dyn_cartpole1l_v2_f64(long K, const void *x, const void *tau, double h, const void *h_pt, void *xnext, void *J, void *stream);
 
 /* cartpole2l (deqmpc/my_envs/cartpole2l/src): q = (cart x, th1, th2 relative to link 1); x[K][6], tau[K][3],
  * xnext[K][6] (nullable), J[K][6][9] = d xnext / d(q, qdot, tau) (nullable). Model: DESIGN.md section 9. */

@@ -80,28 +80,38 @@ static dual6 sin6(dual6 a) { dual6 r; double c = cos(a.v); r.v = sin(a.v); for (
 static dual6 cos6(dual6 a) { dual6 r; double s = -sin(a.v); r.v = cos(a.v); for (int i = 0; i < 6; ++i) r.d[i] = s * a.d[i]; return r; }
 static dual6 inv6(dual6 a) { dual6 r; r.v = 1.0 / a.v; for (int i = 0; i < 6; ++i) r.d[i] = -a.d[i] * r.v * r.v; return r; }
 
+/* The two cartpole1l packages are the same model with different constants:
+ *      M(theta) = [[ma, -mb cos], [-mb cos, md]],  M q'' = tau - (mb sin(theta) theta'^2, 0) + (0, 9.81 mb sin(theta))
+ *   cartpole1l    : ma = 11,  mb = 1,   md = 2     (cart 10 kg + pole 1 kg, m l = 1)
+ *   cartpole1l_v2 : ma = 0.7, mb = 0.1, md = 0.05  (cart 0.5 kg + pole 0.2 kg at l = 0.5: m l = 0.1, m l^2 = 0.05;
+ *                   deqmpc/my_envs/cartpole1l_v2/src/generated_dynamics.c - a package the reference ships but does not
+ *                   import, my_envs/cartpole.py:35; identified from its compiled code like the first one and pinned
+ *                   against its outputs, tests/golden/dyn_cartpole1l_v2.npz) */
+typedef struct { double ma, mb, md; } cart_par;
+static const cart_par CART_V1 = {11.0, 1.0, 2.0}, CART_V2 = {0.7, 0.1, 0.05};
+
 /* accelerations (xdd, thdd) at (theta, thetad, tau) */
-static void cart_acc(dual6 th, dual6 thd, dual6 t0, dual6 t1, dual6 *xdd, dual6 *thdd) {
+static void cart_acc(cart_par p, dual6 th, dual6 thd, dual6 t0, dual6 t1, dual6 *xdd, dual6 *thdd) {
     dual6 sn = sin6(th), cs = cos6(th);
-    dual6 r0 = a6(t0, s6(-1.0, m6(sn, m6(thd, thd))));   /* tau0 - sin(th) thd^2 */
-    dual6 r1 = a6(t1, s6(9.81, sn));                      /* tau1 + 9.81 sin(th)  */
-    dual6 idet = inv6(a6(c6(22.0), s6(-1.0, m6(cs, cs)))); /* det M = 22 - cos^2   */
-    *xdd = m6(idet, a6(s6(2.0, r0), m6(cs, r1)));          /* M^-1 = [[2, c],[c, 11]] / det */
-    *thdd = m6(idet, a6(m6(cs, r0), s6(11.0, r1)));
+    dual6 r0 = a6(t0, s6(-p.mb, m6(sn, m6(thd, thd))));            /* tau0 - mb sin(th) thd^2 */
+    dual6 r1 = a6(t1, s6(9.81 * p.mb, sn));                         /* tau1 + 9.81 mb sin(th)  */
+    dual6 idet = inv6(a6(c6(p.ma * p.md), s6(-p.mb * p.mb, m6(cs, cs)))); /* det M = ma md - mb^2 cos^2 */
+    *xdd = m6(idet, a6(s6(p.md, r0), s6(p.mb, m6(cs, r1))));        /* M^-1 = [[md, mb c],[mb c, ma]] / det */
+    *thdd = m6(idet, a6(s6(p.mb, m6(cs, r0)), s6(p.ma, r1)));
 }
 
 /* one point: q[2], qd[2], tau[2] -> qn[2], qdn[2], J[4][6] = d(qn, qdn)/d(q, qd, tau) */
-void dyn_cartpole1l_point(const double *q, const double *qd, const double *tau, double h, double *xn, double *J) {
+static void dyn_cartpole1l_point_p(cart_par p, const double *q, const double *qd, const double *tau, double h, double *xn, double *J) {
     dual6 x = c6(q[0]), th = c6(q[1]), xd = c6(qd[0]), thd = c6(qd[1]), t0 = c6(tau[0]), t1 = c6(tau[1]);
     x.d[0] = 1; th.d[1] = 1; xd.d[2] = 1; thd.d[3] = 1; t0.d[4] = 1; t1.d[5] = 1;
     dual6 k1x = xd, k1t = thd, k1xd, k1td;
-    cart_acc(th, thd, t0, t1, &k1xd, &k1td);
+    cart_acc(p, th, thd, t0, t1, &k1xd, &k1td);
     dual6 k2x = a6(xd, s6(0.5 * h, k1xd)), k2t = a6(thd, s6(0.5 * h, k1td)), k2xd, k2td;
-    cart_acc(a6(th, s6(0.5 * h, k1t)), k2t, t0, t1, &k2xd, &k2td);
+    cart_acc(p, a6(th, s6(0.5 * h, k1t)), k2t, t0, t1, &k2xd, &k2td);
     dual6 k3x = a6(xd, s6(0.5 * h, k2xd)), k3t = a6(thd, s6(0.5 * h, k2td)), k3xd, k3td;
-    cart_acc(a6(th, s6(0.5 * h, k2t)), k3t, t0, t1, &k3xd, &k3td);
+    cart_acc(p, a6(th, s6(0.5 * h, k2t)), k3t, t0, t1, &k3xd, &k3td);
     dual6 k4x = a6(xd, s6(h, k3xd)), k4t = a6(thd, s6(h, k3td)), k4xd, k4td;
-    cart_acc(a6(th, s6(h, k3t)), k4t, t0, t1, &k4xd, &k4td);
+    cart_acc(p, a6(th, s6(h, k3t)), k4t, t0, t1, &k4xd, &k4td);
     dual6 o[4];
     o[0] = a6(x, s6(h / 6.0, a6(a6(k1x, s6(2.0, k2x)), a6(s6(2.0, k3x), k4x))));
     o[1] = a6(th, s6(h / 6.0, a6(a6(k1t, s6(2.0, k2t)), a6(s6(2.0, k3t), k4t))));
@@ -113,9 +123,16 @@ void dyn_cartpole1l_point(const double *q, const double *qd, const double *tau, 
     }
 }
 
+void dyn_cartpole1l_point(const double *q, const double *qd, const double *tau, double h, double *xn, double *J) {
+    dyn_cartpole1l_point_p(CART_V1, q, qd, tau, h, xn, J);
+}
+
 /* K points: x[K][4] = (q, qd), tau[K][2] -> xn[K][4], J[K][4][6] */
 void dyn_cartpole1l(long K, const double *x, const double *tau, double h, double *xn, double *J) {
-    for (long i = 0; i < K; ++i) dyn_cartpole1l_point(x + 4 * i, x + 4 * i + 2, tau + 2 * i, h, xn + 4 * i, J + 24 * i);
+    for (long i = 0; i < K; ++i) dyn_cartpole1l_point_p(CART_V1, x + 4 * i, x + 4 * i + 2, tau + 2 * i, h, xn + 4 * i, J + 24 * i);
+}
+void dyn_cartpole1l_v2(long K, const double *x, const double *tau, double h, double *xn, double *J) {
+    for (long i = 0; i < K; ++i) dyn_cartpole1l_point_p(CART_V2, x + 4 * i, x + 4 * i + 2, tau + 2 * i, h, xn + 4 * i, J + 24 * i);
 }
 
 

@@ -18,6 +18,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = os.path.join(_HERE, "libdyn_oracle.so")
 _REF = os.path.join(_HERE, "_ref", "libpendulum1l_casadi.so")
 _REF_CP = os.path.join(_HERE, "_ref", "libcartpole1l_casadi.so")
+_REF_CPV2 = os.path.join(_HERE, "_ref", "libcartpole1l_v2_casadi.so")
 _REF_CP2 = os.path.join(_HERE, "_ref", "libcartpole2l_casadi.so")
 
 
@@ -76,7 +77,7 @@ def pendulum1l_ref(x, u, h):
     return xn, A, B
 
 
-def cartpole1l(x, tau, h):
+def cartpole1l(x, tau, h, fn="dyn_cartpole1l"):
     """x [K,4] = (cart x, theta, xdot, thetadot), tau [K,2] -> xn [K,4], J [K,4,6] = d xn / d(q, qd, tau)."""
     build()
     lib = C.CDLL(_LIB)
@@ -85,20 +86,34 @@ def cartpole1l(x, tau, h):
     K = x.shape[0]
     xn, J = np.empty((K, 4)), np.empty((K, 4, 6))
     P = lambda a: a.ctypes.data_as(C.c_void_p)
-    lib.dyn_cartpole1l.argtypes = [C.c_long, C.c_void_p, C.c_void_p, C.c_double, C.c_void_p, C.c_void_p]
-    lib.dyn_cartpole1l(K, P(x), P(tau), float(h), P(xn), P(J))
+    f = getattr(lib, fn)
+    f.argtypes = [C.c_long, C.c_void_p, C.c_void_p, C.c_double, C.c_void_p, C.c_void_p]
+    f(K, P(x), P(tau), float(h), P(xn), P(J))
     return xn, J
+
+
+def cartpole1l_v2(x, tau, h):
+    """The cartpole1l_v2 package's constants (oracle/dyn_oracle.c CART_V2)."""
+    return cartpole1l(x, tau, h, fn="dyn_cartpole1l_v2")
 
 
 def have_ref_cartpole():
     return os.path.exists(_REF_CP)
 
 
-def cartpole1l_ref(x, tau, h):
+def have_ref_cartpole_v2():
+    return os.path.exists(_REF_CPV2)
+
+
+def cartpole1l_v2_ref(x, tau, h):
+    return cartpole1l_ref(x, tau, h, path=_REF_CPV2)
+
+
+def cartpole1l_ref(x, tau, h, path=None):
     """The same through the reference's generated code. Outputs of eval_forward_derivatives are six
     2x2 blocks (dq'/dq, dq'/dqdot, dq'/dtau, dqdot'/dq, dqdot'/dqdot, dqdot'/dtau), each stored
     COLUMN-major (CasADi dense), cf. cartpole1l/src/dynamics_cpu.cpp."""
-    lib = C.CDLL(_REF_CP)
+    lib = C.CDLL(path or _REF_CP)
     x = np.ascontiguousarray(x, np.float64)
     tau = np.ascontiguousarray(tau, np.float64)
     K = x.shape[0]

@@ -205,6 +205,84 @@ def test_hip_cartpole_class_and_package_twin():
     assert np.abs(blocks[4].cpu().numpy() - GOLDC["h05_J"][:, 2:, 2:4]).max() < 5e-13   # dqdot'/dqdot
 
 
+# ---- cartpole1l_v2 (the reference's second one-link package: same model, lighter cart and pole) ----
+GOLDV2 = np.load(os.path.join(os.path.dirname(__file__), "golden", "dyn_cartpole1l_v2.npz"))
+
+
+@pytest.mark.parametrize("tag", ["h05", "h01"])
+def test_cartpole_v2_restatement_matches_reference_vectors(tag):
+    xn, J = dyn_py.cartpole1l_v2(GOLDV2["x"], GOLDV2["tau"], float(GOLDV2[tag + "_h"]))
+    assert np.abs(xn - GOLDV2[tag + "_xn"]).max() < 5e-13      # accelerations are ~15x those of cartpole1l at the same force
+    assert np.abs(J - GOLDV2[tag + "_J"]).max() < 5e-13
+    # and it is NOT the first package's model: the two fixtures differ by far more than any tolerance here
+    assert np.abs(GOLDV2[tag + "_xn"] - GOLDC[tag + "_xn"]).max() > 1e-2
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype,tol", [(torch.float64, 5e-12), (torch.float32, 5e-4)])
+@pytest.mark.parametrize("tag", ["h05", "h01"])
+def test_hip_cartpole_v2_matches_reference_vectors(dtype, tol, tag):
+    from deq_mpc_corl_amd.backend import default_backend
+    be = default_backend()
+    dev = "cuda:0"
+    x = torch.tensor(GOLDV2["x"], dtype=dtype, device=dev)
+    tau = torch.tensor(GOLDV2["tau"], dtype=dtype, device=dev)
+    xn, J = be.dyn_cartpole1l(x, tau, float(GOLDV2[tag + "_h"]), version=2)
+    torch.cuda.synchronize()
+    scale = 1.0 + np.abs(GOLDV2[tag + "_xn"])
+    assert (np.abs(xn.cpu().numpy() - GOLDV2[tag + "_xn"]) / scale).max() < tol
+    assert (np.abs(J.cpu().numpy() - GOLDV2[tag + "_J"]) / (1.0 + np.abs(GOLDV2[tag + "_J"]))).max() < tol
+
+
+@pytest.mark.gpu
+def test_hip_cartpole_v2_class_package_twin_and_mpc():
+    """`Cartpole1lV2Dynamics` / `dynamics.cartpole1l_v2` against the fixture, and an MPC on that model (provider kernels
+    between the solver's launches, nonlinear-caller mode) against the same MPC driven by the CPU restatement."""
+    from deq_mpc_corl_amd import MPC, Cartpole1lV2Dynamics, QuadCost
+    from deq_mpc_corl_amd.dynamics import cartpole1l_v2
+    dev, dt = "cuda:0", torch.float64
+    sel = GOLDV2["tau"][:, 1] == 0
+    x = torch.tensor(GOLDV2["x"][sel], dtype=dt, device=dev)
+    u = torch.tensor(GOLDV2["tau"][sel][:, :1], dtype=dt, device=dev)
+    dyn = Cartpole1lV2Dynamics(dt=0.05)
+    xn, (A, B) = dyn.jac(x, u)
+    assert np.abs(xn.cpu().numpy() - GOLDV2["h05_xn"][sel]).max() < 5e-12
+    assert np.abs(A.cpu().numpy() - GOLDV2["h05_J"][sel][:, :, :4]).max() < 5e-11
+    assert np.abs(B.cpu().numpy() - GOLDV2["h05_J"][sel][:, :, 4:5]).max() < 5e-11
+    xa = torch.tensor(GOLDV2["x"], dtype=dt, device=dev)
+    ta = torch.tensor(GOLDV2["tau"], dtype=dt, device=dev)
+    h = torch.full((xa.shape[0], 1), 0.05, dtype=dt, device=dev)
+    qn, qdn = cartpole1l_v2.dynamics(xa[:, :2].contiguous(), xa[:, 2:].contiguous(), ta, h)
+    assert np.abs(torch.cat((qn, qdn), 1).cpu().numpy() - GOLDV2["h05_xn"]).max() < 5e-12
+    assert len(cartpole1l_v2.derivatives(xa[:, :2].contiguous(), xa[:, 2:].contiguous(), ta, h)) == 6
+
+    class CpuDyn:   # the same model through the CPU restatement (test infrastructure)
+        def __call__(self, xx, uu):
+            o = dyn_py.cartpole1l_v2(xx.detach().cpu().numpy(), np.concatenate([uu.detach().cpu().numpy(), np.zeros((uu.shape[0], 1))], 1), 0.05)[0]
+            return torch.as_tensor(o, dtype=dt, device=xx.device)
+
+        def jac(self, xx, uu):
+            o, Jn = dyn_py.cartpole1l_v2(xx.detach().cpu().numpy(), np.concatenate([uu.detach().cpu().numpy(), np.zeros((uu.shape[0], 1))], 1), 0.05)
+            Jt = torch.as_tensor(Jn, dtype=dt, device=xx.device)
+            return torch.as_tensor(o, dtype=dt, device=xx.device), (Jt[..., :4], Jt[..., 4:5])
+
+    B_, T = 12, 8
+    g = torch.Generator().manual_seed(3)
+    x0 = (0.3 * torch.randn(B_, 4, generator=g, dtype=dt)).to(dev)
+    Qd = torch.cat((torch.full((B_, T, 4), 5.0, dtype=dt), torch.full((B_, T, 1), 1e-2, dtype=dt)), -1).to(dev)
+    q = (0.1 * torch.randn(B_, T, 5, generator=g, dtype=dt)).to(dev)
+    out = []
+    for prov in (dyn, CpuDyn()):
+        mpc = MPC(4, 1, T, u_lower=torch.tensor([-2.0], dtype=dt, device=dev), u_upper=torch.tensor([2.0], dtype=dt, device=dev),
+                  n_batch=B_, dtype=dt)
+        mpc.reinitialize(x0, None)
+        mpc.al_iter = 2
+        xs, us, _ = mpc(x0, QuadCost(torch.diag_embed(Qd), q, torch.zeros(B_, T, dtype=dt, device=dev)), prov, prov.jac)
+        out.append((xs.cpu(), us.cpu(), list(mpc.last_newton_per_al)))
+    assert out[0][2] == out[1][2]
+    assert torch.allclose(out[0][0], out[1][0], atol=1e-6) and torch.allclose(out[0][1], out[1][1], atol=1e-6)
+
+
 # ---- nonlinear fused solve (alqp_solve_nonlin) ----------------------------------------------
 @pytest.mark.gpu
 @pytest.mark.parametrize("env", ["pendulum1l", "cartpole1l", "cartpole2l"])

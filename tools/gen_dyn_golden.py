@@ -41,6 +41,16 @@ np.savez(os.path.join(ROOT, "tests", "golden", "dyn_cartpole1l.npz"), x=xc, tau=
 xn3, J3 = dyn_py.cartpole1l(xc, tc, 0.05)
 print("cartpole1l restatement vs reference (h=0.05): max |dxn| %.2e, |dJ| %.2e" % (
     np.abs(xn3 - outc["h05_xn"]).max(), np.abs(J3 - outc["h05_J"]).max()))
+# ---- cartpole1l_v2 (same model, lighter cart and pole; a package the reference ships but does not import)
+assert dyn_py.have_ref_cartpole_v2(), "oracle/_ref/libcartpole1l_v2_casadi.so missing"
+outv = {}
+for name, h in (("h05", 0.05), ("h01", 0.01)):
+    xn, J = dyn_py.cartpole1l_v2_ref(xc, tc, h)
+    outv.update({f"{name}_h": np.float64(h), f"{name}_xn": xn, f"{name}_J": J})
+np.savez(os.path.join(ROOT, "tests", "golden", "dyn_cartpole1l_v2.npz"), x=xc, tau=tc, **outv)
+xn5, J5 = dyn_py.cartpole1l_v2(xc, tc, 0.05)
+print("cartpole1l_v2 restatement vs reference (h=0.05): max |dxn| %.2e, |dJ| %.2e" % (
+    np.abs(xn5 - outv["h05_xn"]).max(), np.abs(J5 - outv["h05_J"]).max()))
 # ---- cartpole2l
 assert dyn_py.have_ref_cartpole2(), "oracle/_ref/libcartpole2l_casadi.so missing"
 K2 = 384
