@@ -79,24 +79,28 @@ struct DynPendulum1l {
 };
 
 // ---- cartpole1l: x = (cart x, theta, xdot, thetadot), u = force on the cart (tau = (u, 0)) ----
-template <typename real>
+//      M(th) q'' = tau - (mb sin th th'^2, 0) + (0, 9.81 mb sin th), M = [[ma, -mb cos th], [-mb cos th, md]].
+//      V = 1: my_envs/cartpole1l (ma, mb, md) = (11, 1, 2); V = 2: my_envs/cartpole1l_v2 (0.7, 0.1, 0.05)
+template <typename real, int V = 1>
 struct DynCartpole1l {
-    static constexpr int NX = 4, NU = 1, ID = 2;
+    static constexpr int NX = 4, NU = 1, ID = V == 1 ? 2 : 4;
+    static constexpr double MA = V == 1 ? 11.0 : 0.7, MB = V == 1 ? 1.0 : 0.1, MD = V == 1 ? 2.0 : 0.05;
     template <int NT>
     __device__ __forceinline__ static void acc(Dual<real, NT> th, Dual<real, NT> thd, Dual<real, NT> t0, Dual<real, NT> &xdd,
                                                Dual<real, NT> &thdd) {
         using D = Dual<real, NT>;
         D sn, cs;
         dsincos(th, sn, cs);
-        const D r0 = daxpy(t0, real(-1), dmul(sn, dmul(thd, thd)));  // tau0 - sin(th) thd^2
-        const D r1 = daxpy(dconst<real, NT>(0), real(9.81), sn);      // 9.81 sin(th)
-        const D det = daxpy(dconst<real, NT>(real(22)), real(-1), dmul(cs, cs));
+        const D r0 = daxpy(t0, real(-MB), dmul(sn, dmul(thd, thd)));  // tau0 - mb sin(th) thd^2
+        const D r1 = daxpy(dconst<real, NT>(0), real(9.81 * MB), sn);  // 9.81 mb sin(th)
+        const D det = daxpy(dconst<real, NT>(real(MA * MD)), real(-MB * MB), dmul(cs, cs));
         D idet;
         idet.v = real(1) / det.v;
 #pragma unroll
         for (int i = 0; i < NT; ++i) idet.d[i] = -det.d[i] * idet.v * idet.v;
-        xdd = dmul(idet, daxpy(dmul(cs, r1), real(2), r0));    // M^-1 = [[2, c], [c, 11]] / det
-        thdd = dmul(idet, daxpy(dmul(cs, r0), real(11), r1));
+        const D zero = dconst<real, NT>(0);
+        xdd = dmul(idet, daxpy(daxpy(zero, real(MB), dmul(cs, r1)), real(MD), r0));    // M^-1 = [[md, mb c], [mb c, ma]] / det
+        thdd = dmul(idet, daxpy(daxpy(zero, real(MB), dmul(cs, r0)), real(MA), r1));
     }
     template <int NT>
     __device__ __forceinline__ static void step(const Dual<real, NT> (&z)[5], real h, Dual<real, NT> (&xn)[4]) {

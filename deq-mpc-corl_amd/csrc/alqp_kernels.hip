@@ -1008,6 +1008,9 @@ int dispatch_solve_nonlin(int dyn_id, int nx, int nu, const SolveArgs<real> &a, 
     if (dyn_id == DynCartpole1l<real>::ID && nx == 4 && nu == 1)
         return launch_quad_kernel<real, 4, 1>(k_solve_lin_quad<real, 4, 1, false, DynCartpole1l<real>>, a.B, stream, a,
                                               TraceArgs<real>{}, ws);
+    if (dyn_id == DynCartpole1l<real, 2>::ID && nx == 4 && nu == 1)
+        return launch_quad_kernel<real, 4, 1>(k_solve_lin_quad<real, 4, 1, false, DynCartpole1l<real, 2>>, a.B, stream, a,
+                                              TraceArgs<real>{}, ws);
     if (dyn_id == DynCartpole2l<real>::ID && nx == 6 && nu == 1)
         return launch_quad_kernel<real, 6, 1>(k_solve_lin_quad<real, 6, 1, false, DynCartpole2l<real>>, a.B, stream, a,
                                               TraceArgs<real>{}, ws);

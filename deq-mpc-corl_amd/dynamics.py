@@ -100,9 +100,9 @@ class cartpole1l:
 
 class Cartpole1lV2Dynamics(Cartpole1lDynamics):
     """The reference's second one-link cartpole package (`my_envs/cartpole1l_v2`: cart 0.5 kg, pole 0.2 kg at 0.5 m;
-    shipped but not imported by `my_envs/cartpole.py:35`). Same state and action layout; provider kernels only - the
-    model is not compiled into the nonlinear fused solve, so an MPC on it runs in nonlinear-caller mode."""
-    fused_id = None
+    shipped but not imported by `my_envs/cartpole.py:35`). Same state and action layout; also compiled into the
+    nonlinear fused solve (model id 4)."""
+    fused_id = 4
 
     def __call__(self, x, u):
         xn, _ = self._be().dyn_cartpole1l(x.contiguous(), self._tau(u), self.dt, want_jac=False, version=2)

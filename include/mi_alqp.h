@@ -304,7 +304,7 @@ int alqp_dyn_cartpole2l_f64(long K, const void *x, const void *tau, double h, co
  * Nonlinear fused solve: the whole AL solve of MPC.al_solve (AL_mpc.py:260-339) with NONLINEAR
  * dynamics in ONE launch, for the robots whose dynamics model is compiled into the library
  * (dyn_id 1 = pendulum1l (nx=2, nu=1), 2 = cartpole1l (nx=4, nu=1, tau = (u, 0)), 3 = cartpole2l (nx=6, nu=1,
- * tau = (u, 0, 0)); dyn_h = step length).
+ * tau = (u, 0, 0)), 4 = cartpole1l_v2 (as 2, the second package's constants); dyn_h = step length).
  * Replaces the PyTorch round trips of NewtonAL.forward (al_utils.py:451-576): every Newton step
  * re-linearises on the device (dx_jac, :503), the 20 line-search candidates and the dual update
  * are evaluated with the true dynamics (:623-633, AL_mpc.py:315). Arguments as alqp_solve_lin

@@ -285,15 +285,16 @@ def test_hip_cartpole_v2_class_package_twin_and_mpc():
 
 # ---- nonlinear fused solve (alqp_solve_nonlin) ----------------------------------------------
 @pytest.mark.gpu
-@pytest.mark.parametrize("env", ["pendulum1l", "cartpole1l", "cartpole2l"])
+@pytest.mark.parametrize("env", ["pendulum1l", "cartpole1l", "cartpole1l_v2", "cartpole2l"])
 @pytest.mark.parametrize("dtype,tol", [(torch.float64, 5e-7), (torch.float32, 2e-3)])
 def test_fused_nonlinear_solve_equals_the_launch_per_step_path(env, dtype, tol):
     """One launch with the model inlined against the host-driven nonlinear-caller mode (kernel per
     Newton-step phase, provider kernels for dx / dx_jac - the path that is validated against the
     reference's nonlinear goldens), both with exit_mode='fixed'. Active bounds included."""
-    from deq_mpc_corl_amd import MPC, QuadCost, Pendulum1lDynamics, Cartpole1lDynamics, Cartpole2lDynamics
+    from deq_mpc_corl_amd import MPC, QuadCost, Pendulum1lDynamics, Cartpole1lDynamics, Cartpole1lV2Dynamics, Cartpole2lDynamics
     dev = "cuda:0"
-    prov = {"pendulum1l": Pendulum1lDynamics, "cartpole1l": Cartpole1lDynamics, "cartpole2l": Cartpole2lDynamics}[env](0.05)
+    prov = {"pendulum1l": Pendulum1lDynamics, "cartpole1l": Cartpole1lDynamics, "cartpole1l_v2": Cartpole1lV2Dynamics,
+            "cartpole2l": Cartpole2lDynamics}[env](0.05)
     nx, T, B = prov.nx, (6 if env == "pendulum1l" else 9), 70
     n = nx + 1
     g = torch.Generator().manual_seed(11)
@@ -301,7 +302,7 @@ def test_fused_nonlinear_solve_equals_the_launch_per_step_path(env, dtype, tol):
     Qd = (0.5 + torch.rand(B, T, n, generator=g)).to(dtype).to(dev)
     Qd[..., -1] = 0.05
     q = (0.3 * torch.randn(B, T, n, generator=g)).to(dtype).to(dev)
-    ub = 0.4 if env == "pendulum1l" else 3.0          # tight: the bound rows become active
+    ub = {"pendulum1l": 0.4, "cartpole1l_v2": 0.3}.get(env, 3.0)   # tight: the bound rows become active
 
     class Plain:                                        # same kernels, but no fused_id: launch-per-step path
         def __call__(self, x, u):
@@ -325,7 +326,11 @@ def test_fused_nonlinear_solve_equals_the_launch_per_step_path(env, dtype, tol):
         # and x, u are returned in fp32 (AL_mpc.py:337-338): one fp32 ulp
         assert torch.allclose(res["fused"][0], res["stepwise"][0], atol=5e-7)
         assert torch.allclose(res["fused"][1], res["stepwise"][1], atol=5e-7)
-        assert torch.allclose(res["fused"][2], res["stepwise"][2], atol=2e-5, rtol=1e-6)
+        # (cartpole1l_v2: the light cart makes the same force 15x the acceleration - the rounding difference of the two
+        #  factorisations shows up an order of magnitude larger in lam)
+        la, lr = (5e-4, 1e-5) if env == "cartpole1l_v2" else (2e-5, 1e-6)
+        dl = (res["fused"][2] - res["stepwise"][2]).abs()
+        assert bool((dl <= la + lr * res["stepwise"][2].abs()).all()), float(dl.max())
     else:
         # fp32: a near-tie in a 20-point line search may pick another candidate for single instances
         err = (res["fused"][0] - res["stepwise"][0]).abs().reshape(B, -1).max(1).values
