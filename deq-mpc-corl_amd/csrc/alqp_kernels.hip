@@ -114,8 +114,13 @@ __device__ inline unsigned opaque_zero() {
 
 #if ALQP_BUILD_MAIN
 // ---- fused LinDx solve -------------------------------------------------------------
-template <typename real, int NX, int NU, bool TRACE>
-__global__ __launch_bounds__(64, 2) void k_solve_lin(SolveArgs<real> a, TraceArgs<real> tr) {
+// OCC: wavefronts per SIMD the register allocation is capped for. 2 (256 registers) lets a CU hold the 8 teams its
+// LDS has room for, but costs 80 B (fp32) / 252 B (fp64) of scratch per lane at (13,4); 1 (no cap) has no scratch.
+// Measured (profiles/r02/experiments): fp64 is faster uncapped at every batch the team kernels see (B = 200: 1.27 ->
+// 1.22 ms, B = 2048: 3.43 -> 2.85 ms); fp32 only while there is at most one wavefront per SIMD anyway (B = 200: 0.84 ->
+// 0.80 ms, B = 1024: 0.91 -> 0.87 ms; B = 2048: 1.07 against 1.71 ms). dispatch_solve() picks accordingly.
+template <typename real, int NX, int NU, bool TRACE, int OCC = 2>
+__global__ __launch_bounds__(64, OCC) void k_solve_lin(SolveArgs<real> a, TraceArgs<real> tr) {
     if (a.skip && *a.skip != 0.0) return;  // block-uniform, before any barrier
     using C = Cfg<real, NX, NU>;
     constexpr int G = C::G, N = C::N;
@@ -946,12 +951,28 @@ int launch_team_kernel(Fn fn, int B, int T, hipStream_t stream, Args... args) {
     return launch_maybe_coop(fn, grid, lds, stream, args...);
 }
 
+inline long team_simds() {   // SIMDs of the device (4 per CU)
+    static long n = 0;
+    if (n == 0) {
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) != hipSuccess ||
+            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+            cus = 256;
+        n = 4L * cus;
+    }
+    return n;
+}
+
 template <typename real>
 int dispatch_solve(int nx, int nu, const SolveArgs<real> &a, const TraceArgs<real> *tr, hipStream_t stream) {
 #define X(NX, NU)                                                                                     \
     if (nx == NX && nu == NU) {                                                                       \
         if (tr) return launch_team_kernel<real, NX, NU>(k_solve_lin<real, NX, NU, true>, a.B, a.T, stream, a, *tr); \
-        return launch_team_kernel<real, NX, NU>(k_solve_lin<real, NX, NU, false>, a.B, a.T, stream, a, TraceArgs<real>{}); \
+        const long waves = (a.B + Cfg<real, NX, NU>::QPW - 1) / Cfg<real, NX, NU>::QPW;                \
+        if (sizeof(real) == 8 || waves <= team_simds())                                                 \
+            return launch_team_kernel<real, NX, NU>(k_solve_lin<real, NX, NU, false, 1>, a.B, a.T, stream, a, TraceArgs<real>{}); \
+        if constexpr (sizeof(real) == 4)                                                                \
+            return launch_team_kernel<real, NX, NU>(k_solve_lin<real, NX, NU, false, 2>, a.B, a.T, stream, a, TraceArgs<real>{}); \
     }
     ALQP_FOR_EACH_DIMS(X)
 #undef X
