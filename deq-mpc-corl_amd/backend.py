@@ -155,10 +155,10 @@ class HipBackend:
         """AlqpParams fields of ALQP_EXIT_IN_KERNEL: the cached scratch (arrival counter + 2 x B partial sums)."""
         key = ("exit", device)
         scr = self._ws.get(key)
-        if scr is None or scr.numel() < 2 * B + 1:
-            scr = torch.zeros(2 * B + 1, dtype=torch.float64, device=device)
+        if scr is None or scr.numel() < 2 * B + 2:
+            scr = torch.zeros(2 * B + 2, dtype=torch.float64, device=device)
             self._ws[key] = scr
-        scr[:1].zero_()   # the grid barrier's arrival counter
+        scr.zero_()   # arrival counter, partial sums, time-out flag
         p.flags |= _lib.ALQP_EXIT_IN_KERNEL
         p.exit_tol = float(exit_tol)
         p.newton_counts = _ptr(newton_counts, "newton_counts", torch.int32).value

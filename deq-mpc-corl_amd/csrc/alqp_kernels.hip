@@ -43,7 +43,7 @@ struct SolveArgs {
     // ALQP_EXIT_IN_KERNEL (cooperative launch): the reference's batch-global exit test of the Newton loop inside the launch
     double exit_tol;
     int *newton_counts;    // [al_iter] executed Newton steps per AL iteration
-    double *exit_scratch;  // arrival counter, then [2][gridDim.x] per-workgroup partial sums (ping-pong)
+    double *exit_scratch;  // arrival counter, then [2][gridDim.x] per-workgroup partial sums (ping-pong), then a time-out flag
 };
 
 // sum of one value per workgroup over the whole (cooperatively launched) grid, the same bits in every lane of every
@@ -60,15 +60,29 @@ __device__ inline double grid_sum_ordered(double block_val, double *scratch, int
         __builtin_amdgcn_s_waitcnt(0);   // the partial has reached the coherence point before the arrival is counted
         __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const unsigned target = (unsigned)(phase + 1) * gridDim.x;
-        while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) __builtin_amdgcn_s_sleep(2);
+        // bounded spin (~1 s): every wavefront reaches an exit even if an arrival never shows up; the caller then sees NaN,
+        // never takes the early exit and reports -1 Newton steps, which the host turns into an error
+        long spins = 0;
+        while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target && spins < (1L << 23)) {
+            __builtin_amdgcn_s_sleep(2);
+            ++spins;
+        }
+        if (spins >= (1L << 23)) __hip_atomic_store(scratch + 1 + 2 * (size_t)gridDim.x, 1.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     __builtin_amdgcn_s_barrier();   // one wavefront per workgroup: re-converges the lanes behind lane 0's spin
+    if (__hip_atomic_load(scratch + 1 + 2 * (size_t)gridDim.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0.0) {
+        ++phase;
+        return __builtin_nan("");
+    }
     double s = 0;
     for (unsigned i = threadIdx.x; i < gridDim.x; i += 64) s += __hip_atomic_load(p + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
     for (int off = 32; off; off >>= 1) s += __shfl_xor(s, off, 64);
     ++phase;
     return s;
+}
+__device__ inline bool grid_barrier_timed_out(const double *scratch) {
+    return __hip_atomic_load(scratch + 1 + 2 * (size_t)gridDim.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0.0;
 }
 // one value per lane group (teams / quads: `leader` marks one lane per instance) -> the workgroup's sum, fixed order
 __device__ inline double wave_sum_leaders(double v, bool leader) {
@@ -242,7 +256,7 @@ __global__ __launch_bounds__(64, OCC) void k_solve_lin(SolveArgs<real> a, TraceA
                 nrm_old = nw;
             }
         }
-        if (ref_exit && a.newton_counts && blockIdx.x == 0 && lane == 0) a.newton_counts[it] = n_done;
+        if (ref_exit && a.newton_counts && blockIdx.x == 0 && lane == 0) a.newton_counts[it] = grid_barrier_timed_out(a.exit_scratch) ? -1 : n_done;
         if (a.flags & ALQP_DUAL_UPDATE) {
             if (active) tm.dual_update();  // in-place on global lam: padding teams must not touch it
             tm.rho *= a.rho_scale;
@@ -461,7 +475,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
                 nrm_old = nw;
             }
         }
-        if (ref_exit && a.newton_counts && blockIdx.x == 0 && lane == 0) a.newton_counts[it] = n_done;
+        if (ref_exit && a.newton_counts && blockIdx.x == 0 && lane == 0) a.newton_counts[it] = grid_barrier_timed_out(a.exit_scratch) ? -1 : n_done;
         bad = 0;
         qd.template iter_end<Dyn>(alpha_pend, pend, (a.flags & ALQP_DUAL_UPDATE) != 0, (real)a.rho_scale, it + 1 == a.al_iter,
                     phi_next, rn2, bad);

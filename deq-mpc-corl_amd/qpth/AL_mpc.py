@@ -755,6 +755,9 @@ class MPC(Module):
                                 else torch.tensor(float(v), dtype=torch.float64, device=st.z.device)
                                 for v in npa]).tolist()
             npa = [int(round(v)) for v in vals]
+            if min(npa) < 0:
+                raise RuntimeError("mi_alqp: a grid barrier of the in-kernel exit test timed out (ALQP_EXIT_IN_KERNEL); "
+                                   "construct the MPC with exit_in_kernel=False")
         st.newton_per_al = npa
         self.last_status = ws["status"].bool()
         self.last_info = ws["info"]

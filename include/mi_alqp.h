@@ -88,8 +88,9 @@ typedef struct AlqpParams {
                          reference's Newton loop taken on the device, no host round trip) */
     /* ALQP_EXIT_IN_KERNEL only (ignored otherwise): */
     double exit_tol;      /* reference: 1e-3 (al_utils.py:552, 560) */
-    int *newton_counts;   /* nullable DEVICE [al_iter]: executed Newton steps per AL iteration */
-    double *exit_scratch; /* DEVICE, at least 2 * B + 1 doubles; the first one zeroed before every call */
+    int *newton_counts;   /* nullable DEVICE [al_iter]: executed Newton steps per AL iteration (-1: barrier time-out) */
+    double *exit_scratch; /* DEVICE, at least 2 * B + 2 doubles, zeroed before every call (arrival counter, partial sums,
+                             time-out flag: a grid barrier that waited ~1 s gives up, newton_counts then holds -1) */
 } AlqpParams;
 
 /* optional per-step trace (all nullable, for tests): S = al_iter*max_newton steps */
