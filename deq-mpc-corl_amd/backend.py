@@ -117,7 +117,10 @@ class HipBackend:
             variant = self.default_variant
         vnum = {"auto": 0, "team": 1, "quad": 2}[variant]
         if vnum == 0:
-            vnum = 1 if ((flags & _lib.ALQP_SAVE_FACTOR) or B < self.QUAD_MIN_BATCH) else 2
+            # fp64 solve: the team kernels (uncapped build, round 2) hold on a little longer: 5.56 against 6.01 ms at
+            # B = 4096, 6.94 against 6.25 ms at B = 5120
+            qmin = self.QUAD_MIN_BATCH if dt != torch.float64 or self.QUAD_MIN_BATCH != 4096 else 4608
+            vnum = 1 if ((flags & _lib.ALQP_SAVE_FACTOR) or B < qmin) else 2
             if vnum == 1 and not (flags & _lib.ALQP_SAVE_FACTOR) and not self.lib.alqp_supported_variant(C.byref(d), int(dt == torch.float64), 1):
                 vnum = 2   # horizon too long for the team's LDS image: the quad kernels run it at any batch
         ws, ws_bytes = (None, 0)

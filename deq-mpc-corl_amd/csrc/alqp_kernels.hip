@@ -1192,13 +1192,14 @@ int solve_lin_impl(const AlqpDims *dims, const AlqpParams *prm, const void *Qd, 
     const size_t need = quad_ws_bytes<real>(dims->nx, dims->nu, dims->B, dims->T);
     int variant = prm->variant;
     // auto: quad once the batch fills the chip (16 instances per wavefront, 1024 SIMDs), team below
-    // (2-2.4x lower latency at small batches; measured crossover at (13,4) T=20: B = 4096)
+    // (2-2.4x lower latency at small batches; measured crossover at (13,4) T=20: B = 4096 in fp32, ~4600 in fp64)
     if (variant == 0) {
         const size_t team_lds = lds_query<real>(dims->nx, dims->nu, dims->T);
         const bool team_fits = team_lds > 0 && team_lds <= kMaxLds;
         const bool quad_ok = need > 0 && workspace && ws_bytes >= need && !(prm->flags & ALQP_SAVE_FACTOR);
         // long horizons whose factor does not fit the team's LDS image run on the quad kernels at any batch
-        variant = (quad_ok && (dims->B >= 4096 || !team_fits)) ? 2 : 1;
+        const int qmin = sizeof(real) == 8 ? 4608 : 4096;   // fp64: the uncapped team build wins up to ~4.5 k instances
+        variant = (quad_ok && (dims->B >= qmin || !team_fits)) ? 2 : 1;
     }
     if (variant == 2) {
         if (prm->flags & ALQP_SAVE_FACTOR) return ALQP_E_UNSUPPORTED;
