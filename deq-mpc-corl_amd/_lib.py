@@ -13,7 +13,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MI_ALQP_LIB") or os.path.join(_HERE, "csrc", "libmi_alqp.so")   # MI_ALQP_LIB: A/B experiments with a second build of the same ABI
 
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 
 class AlqpDims(C.Structure):
@@ -37,7 +37,11 @@ class AlqpObstacles(C.Structure):
 
 
 class AlqpIpmParams(C.Structure):
-    _fields_ = [("flags", C.c_int), ("max_iter", C.c_int), ("iter0", C.c_int), ("kkt_eps", C.c_double)]
+    _fields_ = [("flags", C.c_int), ("max_iter", C.c_int), ("iter0", C.c_int), ("kkt_eps", C.c_double),
+                ("variant", C.c_int)]
+
+
+IPM_VARIANTS = {"auto": 0, "generic_lds": 1, "generic_ws": 2, "resident": 3}   # ALQP_IPM_VARIANT_*
 
 
 ALQP_IPM_INIT, ALQP_IPM_RESID, ALQP_IPM_STEP, ALQP_IPM_LOOP, ALQP_IPM_FINAL = 1, 2, 4, 8, 16
@@ -87,7 +91,7 @@ _SIGS = {
                                  C.c_long, C.c_long, C.c_long, C.c_long, C.c_long, C.c_long, _P, C.c_size_t, _P,
                                  _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "alqp_ipm_backward": (C.c_int, [C.POINTER(AlqpDims), _P, _P, C.c_long, C.c_long, C.c_long, C.c_long, _P, _P, _P,
-                                    _P, C.c_size_t, _P, _P, _P, _P, _P]),
+                                    _P, C.c_size_t, _P, _P, _P, _P, C.c_int, _P]),
 }
 _PLAIN = {
     "alqp_abi_version": (C.c_int, []),
@@ -99,7 +103,6 @@ _PLAIN = {
     "alqp_exit_test": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_void_p]),
     "alqp_workspace_bytes_nonlin": (C.c_size_t, [C.POINTER(AlqpDims), C.c_int]),
     "alqp_ipm_workspace_bytes": (C.c_size_t, [C.POINTER(AlqpDims), C.c_int]),
-    "alqp_ipm_set_factor_placement": (C.c_int, [C.c_int]),
     "alqp_set_quad_stagger": (C.c_int, [C.c_int]),
 }
 

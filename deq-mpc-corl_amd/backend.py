@@ -425,14 +425,19 @@ class HipBackend:
             self._ws[key] = ws
         return ws, need
 
+    ipm_variant = "auto"   # default kernel of ipm_solve / ipm_backward: a key of _lib.IPM_VARIANTS (include/mi_alqp.h)
+
     def ipm_solve(self, dims, Cd, c, F, f, x0, uhi, ulo, exit_mode="reference", eps=1e-12, not_improved_lim=3,
-                  max_iter=20, ry_fn=None, kkt_eps=1e-7, process_group=None, sharded=False):
+                  max_iter=20, ry_fn=None, kkt_eps=1e-7, process_group=None, sharded=False, variant=None):
         """pdipm_b_LU.forward (batch_LU.py:29-197) on time-major data: Cd, c [T,B,n]; F [T-1,B,nx,n];
         f [T-1,B,nx]; x0 [B,nx]; uhi, ulo [nu]. ry_fn(z [B,T*n]) -> [B,T*nx]: equality residual of the TRUE
         dynamics (one launch per iteration, PyTorch call in between), or None for A z - b.
         exit_mode "fixed" (and no ry_fn): ONE launch for the whole solve. "reference": the reference's
         batch-global exit rule, one host read per iteration (the reference syncs there as well); with `sharded`
-        the three batch-global quantities are max-reduced over the ranks of `process_group` first."""
+        the three batch-global quantities are max-reduced over the ranks of `process_group` first.
+        variant: "auto" (the register/LDS-resident kernel when T <= 20, else the generic one), "generic_lds",
+        "generic_ws", "resident" (AlqpIpmParams.variant); None: self.ipm_variant."""
+        vnum = _lib.IPM_VARIANTS[variant or self.ipm_variant]
         B, T, nx, nu = dims
         n = nx + nu
         dt, dev = c.dtype, c.device
@@ -450,7 +455,7 @@ class HipBackend:
                 _ptr(uhi, "u_upper", dt), _ptr(ulo, "u_lower", dt), B * n, n, B * nx * n, nx * n, B * nx, nx)
 
         def launch(flags, iters=0, it0=0, ry=None):
-            p = _lib.AlqpIpmParams(flags, iters, it0, kkt_eps)
+            p = _lib.AlqpIpmParams(flags, iters, it0, kkt_eps, vnum)
             rc = fn(C.byref(d), C.byref(p), *ptrs, _ptr(ws, "workspace", dt), need, _ptr(ry, "ry", dt, True),
                     _ptr(out["zhat"], "zhat", dt), _ptr(out["nus"], "nus", dt), _ptr(out["lams"], "lams", dt),
                     _ptr(out["slacks"], "slacks", dt), _ptr(out["resid"], "resid", dt), _ptr(mu, "mu", dt), None,
@@ -485,8 +490,9 @@ class HipBackend:
         out["iters"] = done
         return out
 
-    def ipm_backward(self, dims, Cd, F, lams, slacks, g):
+    def ipm_backward(self, dims, Cd, F, lams, slacks, g, variant=None):
         """DenseQPFunction.backward's KKT solve (qp.py:243-252) -> dx [B,T*n], dlam [B,2*T*nu], dnu [B,T*nx]."""
+        vnum = _lib.IPM_VARIANTS[variant or self.ipm_variant]
         B, T, nx, nu = dims
         n = nx + nu
         dt, dev = g.dtype, g.device
@@ -499,7 +505,7 @@ class HipBackend:
         fn = getattr(self.lib, "alqp_ipm_backward_" + sfx)
         rc = fn(C.byref(d), _ptr(Cd, "Cd", dt), _ptr(F, "F", dt), B * n, n, B * nx * n, nx * n, _ptr(lams, "lams", dt),
                 _ptr(slacks, "slacks", dt), _ptr(g, "gbar", dt), _ptr(ws, "workspace", dt), need, _ptr(dx, "dx", dt),
-                _ptr(dlam, "dlam", dt), _ptr(dnu, "dnu", dt), None, _stream())
+                _ptr(dlam, "dlam", dt), _ptr(dnu, "dnu", dt), None, vnum, _stream())
         _lib.check(rc, "alqp_ipm_backward_" + sfx)
         return dx, dlam, dnu
 

@@ -23,48 +23,11 @@
 #include <hip/hip_runtime.h>
 
 #include "alqp_dims.hpp"
+#include "alqp_ipm_args.hpp"
+#include "alqp_ipm_g4_launch.hpp"
 #include "mi_alqp.h"
 
 namespace alqp_ipm {
-
-template <typename real>
-struct IpmArgs {
-    int B, T;
-    int flags;       // ALQP_IPM_*
-    int max_iter;    // iterations done by THIS launch when ALQP_IPM_LOOP is set
-    int iter0;       // index of the first iteration of this launch (for iter_best)
-    real e;          // KKTeps (0 in the backward solve)
-    const real *Cd, *c, *F, *f, *x0, *uhi, *ulo;
-    long sC_t, sC_b, sF_t, sF_b, sf_t, sf_b;   // element strides (stage, instance) of Cd/c, F, f
-    real *ws;        // [B][ws_words]
-    long ws_words;
-    const real *ry_ext;   // nullable [B][T*nx]: equality residual supplied by the caller (true dynamics)
-    const real *gbar;     // backward: [B][T*n]
-    real *o_x, *o_y, *o_z, *o_s;   // outputs: zhat/nus/lams/slacks (or dx / dnu / dlam / - in backward)
-    real *o_resid, *o_mu;
-    int *o_iter_best, *o_improved, *o_info;
-};
-
-template <typename real, int NX, int NU>
-struct Lay {
-    static constexpr int N = NX + NU;
-    int T, nz, ni, ne, NK;
-    long cur, best, res, da, dc, rr, r2, pinv, dt, wv, r1, scal, fac, total;
-    __host__ __device__ Lay(int T_, bool fac_in_ws) : T(T_) {
-        nz = T * N; ni = 2 * T * NU; ne = T * NX; NK = nz + 2 * ni + ne;
-        long o = 0;
-        cur = o; o += NK; best = o; o += NK; res = o; o += NK; da = o; o += NK; dc = o; o += NK;
-        rr = o; o += NK; r2 = o; o += NK; pinv = o; o += nz; dt = o; o += ni; wv = o; o += ni; r1 = o; o += nz;
-        scal = o; o += 8; fac = o;
-        if (fac_in_ws) o += 2L * T * NX * NX;
-        total = (o + 15) & ~15L;
-    }
-    // offsets inside an NK block, reference order (x, s, z, y)
-    __host__ __device__ int ox() const { return 0; }
-    __host__ __device__ int os() const { return nz; }
-    __host__ __device__ int oz() const { return nz + ni; }
-    __host__ __device__ int oy() const { return nz + 2 * ni; }
-};
 
 // LDS image: [factor (optional)] [F tile NX*N] [Pinv tile 2N] [S NX*NX] [W NX*NX] [v T*NX]
 template <typename real, int NX, int NU>
@@ -659,17 +622,14 @@ constexpr size_t kLdsLimit = 64 * 1024;   // per-workgroup LDS the launch may as
 // Where the Schur factor lives. LDS: lowest latency per QP, but 27 / 54 KB (fp32 / fp64 at (20,13,4)) leave 5 / 2
 // wavefronts per CU. Workspace (L2 / Infinity Cache): every sweep stage waits on a global round trip, but the
 // launch then runs 8 wavefronts per CU (register-limited) and hides it - faster as soon as the batch fills the
-// chip that way (measured). ALQP_IPM_FAC: 0 auto, 1 always LDS, 2 always workspace.
-#ifndef ALQP_IPM_FAC
-#define ALQP_IPM_FAC 0
-#endif
-static int g_ipm_fac_mode = ALQP_IPM_FAC;
+// chip that way (measured). fac_mode (AlqpIpmParams.variant 1 / 2): 0 auto, 1 always LDS,
+// 2 always workspace.
 template <typename real, int NX, int NU>
 static bool fac_fits_lds(int T) { return lds_words<real, NX, NU>(T, true) * sizeof(real) <= kLdsLimit; }
 template <typename real, int NX, int NU>
-static bool fac_in_lds(int T, int B) {
-    if (!fac_fits_lds<real, NX, NU>(T) || g_ipm_fac_mode == 2) return false;
-    if (g_ipm_fac_mode == 1) return true;
+static bool fac_in_lds(int T, int B, int fac_mode) {
+    if (!fac_fits_lds<real, NX, NU>(T) || fac_mode == 2) return false;
+    if (fac_mode == 1) return true;
     // auto: LDS while it still allows >= 4 wavefronts per CU (160 KB), or when the batch is too small to
     // fill the chip with enough wavefronts to hide the workspace latency. Measured at (20,13,4), B = 8192:
     // fp64 (2 per CU in LDS) 65 k -> 106 k QP/s in the workspace; fp32 (5 per CU in LDS) 160 k vs 140 k; B = 512:
@@ -692,8 +652,8 @@ static size_t ws_bytes(int nx, int nu, int B, int T) {
 }
 
 template <typename real, int NX, int NU>
-static int launch(IpmArgs<real> a, const real *lams, const real *slacks, bool backward, hipStream_t stream) {
-    const bool fl = fac_in_lds<real, NX, NU>(a.T, a.B);
+static int launch(IpmArgs<real> a, const real *lams, const real *slacks, bool backward, int fac_mode, hipStream_t stream) {
+    const bool fl = fac_in_lds<real, NX, NU>(a.T, a.B, fac_mode);
     a.ws_words = (long)ws_words_for<real, NX, NU>(a.T);
     const size_t lds = lds_words<real, NX, NU>(a.T, fl) * sizeof(real);
     if (lds > kLdsLimit) return ALQP_E_UNSUPPORTED;
@@ -715,11 +675,27 @@ static int launch(IpmArgs<real> a, const real *lams, const real *slacks, bool ba
     return hipGetLastError() == hipSuccess ? 0 : ALQP_E_LAUNCH;
 }
 
+static int g4_launch(int nx, int nu, const IpmArgs<double> &a, const double *l, const double *s, bool bw, hipStream_t st) {
+    return alqp_ipm_g4::launch_f64(nx, nu, a, l, s, bw, (void *)st);
+}
+static int g4_launch(int nx, int nu, const IpmArgs<float> &a, const float *l, const float *s, bool bw, hipStream_t st) {
+    return alqp_ipm_g4::launch_f32(nx, nu, a, l, s, bw, (void *)st);
+}
+
+// variant (AlqpIpmParams.variant): 0 auto - the register/LDS-resident kernel (alqp_ipm_g4.hpp) whenever the problem
+// fits it (T <= 20), else the generic kernel with its automatic factor placement; 1 / 2 the generic kernel with
+// the factor in LDS / in the workspace; 3 the register-resident kernel or ALQP_E_UNSUPPORTED.
 template <typename real>
 static int dispatch(int nx, int nu, const IpmArgs<real> &a, const real *lams, const real *slacks, bool backward,
-                    hipStream_t stream) {
+                    int variant, hipStream_t stream) {
+    if (variant < 0 || variant > 3) return ALQP_E_BADARG;
+    if (variant == 0 || variant == 3) {
+        const int rc = g4_launch(nx, nu, a, lams, slacks, backward, stream);
+        if (rc != ALQP_E_UNSUPPORTED || variant == 3) return rc;
+    }
+    const int fac_mode = variant == 0 ? 0 : variant;
 #define X(NX, NU) \
-    if (nx == NX && nu == NU) return launch<real, NX, NU>(a, lams, slacks, backward, stream);
+    if (nx == NX && nu == NU) return launch<real, NX, NU>(a, lams, slacks, backward, fac_mode, stream);
     ALQP_FOR_EACH_DIMS(X)
 #undef X
     return ALQP_E_UNSUPPORTED;
@@ -748,13 +724,13 @@ static int solve_impl(const AlqpDims *d, const AlqpIpmParams *p, const void *Cd,
     a.ws = (real *)ws; a.ry_ext = (const real *)ry_ext;
     a.o_x = (real *)zhat; a.o_y = (real *)nus; a.o_z = (real *)lams; a.o_s = (real *)slacks;
     a.o_resid = (real *)resid; a.o_mu = (real *)mu; a.o_iter_best = iter_best; a.o_improved = improved; a.o_info = info;
-    return dispatch<real>(d->nx, d->nu, a, nullptr, nullptr, false, (hipStream_t)stream);
+    return dispatch<real>(d->nx, d->nu, a, nullptr, nullptr, false, p->variant, (hipStream_t)stream);
 }
 
 template <typename real>
 static int backward_impl(const AlqpDims *d, const void *Cd, const void *F, long sC_t, long sC_b, long sF_t, long sF_b,
                          const void *lams, const void *slacks, const void *gbar, void *ws, size_t ws_bytes_, void *dx,
-                         void *dlam, void *dnu, int *info, void *stream) {
+                         void *dlam, void *dnu, int *info, int variant, void *stream) {
     if (!dims_ok(d) || !Cd || !F || !lams || !slacks || !gbar || !ws || !dx || !dlam || !dnu) return ALQP_E_BADARG;
     const size_t need = ws_bytes<real>(d->nx, d->nu, d->B, d->T);
     if (need == 0) return ALQP_E_UNSUPPORTED;
@@ -764,18 +740,12 @@ static int backward_impl(const AlqpDims *d, const void *Cd, const void *F, long 
     a.Cd = (const real *)Cd; a.F = (const real *)F; a.sC_t = sC_t; a.sC_b = sC_b; a.sF_t = sF_t; a.sF_b = sF_b;
     a.ws = (real *)ws; a.gbar = (const real *)gbar;
     a.o_x = (real *)dx; a.o_z = (real *)dlam; a.o_y = (real *)dnu; a.o_info = info;
-    return dispatch<real>(d->nx, d->nu, a, (const real *)lams, (const real *)slacks, true, (hipStream_t)stream);
+    return dispatch<real>(d->nx, d->nu, a, (const real *)lams, (const real *)slacks, true, variant, (hipStream_t)stream);
 }
 
 }  // namespace alqp_ipm
 
 extern "C" {
-
-int alqp_ipm_set_factor_placement(int mode) {
-    if (mode < 0 || mode > 2) return ALQP_E_BADARG;
-    alqp_ipm::g_ipm_fac_mode = mode;
-    return 0;
-}
 
 size_t alqp_ipm_workspace_bytes(const AlqpDims *dims, int is_f64) {
     if (!alqp_ipm::dims_ok(dims)) return 0;
@@ -796,9 +766,9 @@ size_t alqp_ipm_workspace_bytes(const AlqpDims *dims, int is_f64) {
     int alqp_ipm_backward_##SFX(const AlqpDims *dims, const void *Cd, const void *F, long sC_t, long sC_b,          \
                                 long sF_t, long sF_b, const void *lams, const void *slacks, const void *gbar,       \
                                 void *workspace, size_t ws_bytes, void *dx, void *dlam, void *dnu, int *info,       \
-                                void *stream) {                                                                     \
+                                int variant, void *stream) {                                                        \
         return alqp_ipm::backward_impl<REAL>(dims, Cd, F, sC_t, sC_b, sF_t, sF_b, lams, slacks, gbar, workspace,    \
-                                             ws_bytes, dx, dlam, dnu, info, stream);                                \
+                                             ws_bytes, dx, dlam, dnu, info, variant, stream);                       \
     }
 
 ALQP_IPM_DEFINE(f32, float)

@@ -1,0 +1,75 @@
+// alqp_ipm_g4.hip - launchers of the register/LDS-resident interior-point kernel (alqp_ipm_g4.hpp on the gfx950
+// policy alqp_ipm_g4_gpu.hpp). Compiled once per dtype (-DALQP_G4_F64 / -DALQP_G4_F32); alqp_ipm.hip dispatches
+// here when the horizon fits the register slots (T <= 20) and falls back to its size-generic kernel otherwise.
+#include <hip/hip_runtime.h>
+
+#include "alqp_dims.hpp"
+#include "alqp_ipm_g4_gpu.hpp"
+#include "alqp_ipm_g4_launch.hpp"
+
+namespace alqp_ipm_g4 {
+
+constexpr int kSlots = 5;   // stage slots per lane group: T <= 4 * kSlots
+
+template <typename real, int NX, int NU>
+__global__ __launch_bounds__(64) void k_ipm_g4(const IpmArgs<real> a) {
+    extern __shared__ __align__(16) unsigned char lds_raw[];
+    const int b = blockIdx.x;
+    if (b >= a.B) return;
+    Solver<real, NX, NU, kSlots, GpuX<real>> S(a, reinterpret_cast<real *>(lds_raw), b);
+    S.run_forward();
+}
+
+template <typename real, int NX, int NU>
+__global__ __launch_bounds__(64) void k_ipm_g4_backward(const IpmArgs<real> a, const real *lams, const real *slacks) {
+    extern __shared__ __align__(16) unsigned char lds_raw[];
+    const int b = blockIdx.x;
+    if (b >= a.B) return;
+    Solver<real, NX, NU, kSlots, GpuX<real>> S(a, reinterpret_cast<real *>(lds_raw), b);
+    S.run_backward(lams, slacks);
+}
+
+constexpr size_t kLdsMax = 64 * 1024;
+
+template <typename real, int NX, int NU>
+static int launch(IpmArgs<real> a, const real *lams, const real *slacks, bool backward, hipStream_t stream) {
+    using S = Solver<real, NX, NU, kSlots, GpuX<real>>;
+    // what the kernel's 32-bit lane indices can address (element offsets inside one instance's strided inputs)
+    const long span = (long)a.T * (a.sC_t > a.sF_t ? a.sC_t : a.sF_t);
+    if (a.T > S::TMAX || a.T < 2 || span >= (1L << 31)) return ALQP_E_UNSUPPORTED;
+    const size_t lds = (size_t)S::lds_words(a.T) * sizeof(real);
+    if (lds > kLdsMax) return ALQP_E_UNSUPPORTED;
+    a.ws_words = Lay<real, NX, NU>(a.T, true).total;
+    const void *kf = backward ? reinterpret_cast<const void *>(k_ipm_g4_backward<real, NX, NU>)
+                              : reinterpret_cast<const void *>(k_ipm_g4<real, NX, NU>);
+    if (lds > 48 * 1024 && hipFuncSetAttribute(kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        return ALQP_E_LAUNCH;
+    if (backward) hipLaunchKernelGGL((k_ipm_g4_backward<real, NX, NU>), dim3(a.B), dim3(64), lds, stream, a, lams, slacks);
+    else hipLaunchKernelGGL((k_ipm_g4<real, NX, NU>), dim3(a.B), dim3(64), lds, stream, a);
+    return hipGetLastError() == hipSuccess ? 0 : ALQP_E_LAUNCH;
+}
+
+template <typename real>
+static int dispatch(int nx, int nu, const IpmArgs<real> &a, const real *lams, const real *slacks, bool backward,
+                    hipStream_t stream) {
+#define X(NX, NU) \
+    if (nx == NX && nu == NU) return launch<real, NX, NU>(a, lams, slacks, backward, stream);
+    ALQP_FOR_EACH_DIMS(X)
+#undef X
+    return ALQP_E_UNSUPPORTED;
+}
+
+#ifdef ALQP_G4_F64
+int launch_f64(int nx, int nu, const IpmArgs<double> &a, const double *lams, const double *slacks, bool backward,
+               void *stream) {
+    return dispatch<double>(nx, nu, a, lams, slacks, backward, (hipStream_t)stream);
+}
+#endif
+#ifdef ALQP_G4_F32
+int launch_f32(int nx, int nu, const IpmArgs<float> &a, const float *lams, const float *slacks, bool backward,
+               void *stream) {
+    return dispatch<float>(nx, nu, a, lams, slacks, backward, (hipStream_t)stream);
+}
+#endif
+
+}  // namespace alqp_ipm_g4

@@ -1614,7 +1614,7 @@ __global__ void k_exit_test(const double *sumsq, double *ctl, int mode, double t
 #if ALQP_BUILD_MAIN
 extern "C" {
 
-int alqp_abi_version(void) { return 9; }
+int alqp_abi_version(void) { return 10; }
 
 int alqp_set_quad_stagger(int mode) {
     const int prev = alqp::g_stagger_mode;

@@ -1,7 +1,8 @@
 #!/bin/bash
 # Builds libmi_alqp.so for gfx950 (MI355X). hipcc cross-compiles without a GPU.
 # alqp_kernels.hip is compiled as three objects in parallel (team+ABI, quad fp32, quad fp64),
-# alqp_ipm.hip (interior-point path) as a fourth.
+# alqp_ipm.hip (interior-point path, generic kernel + ABI) as a fourth, alqp_ipm_g4.hip (its register-resident kernel)
+# once per dtype.
 set -euo pipefail
 cd "$(dirname "$0")"
 # -pragma-unroll-threshold: the panel loops of alqp_quad.hpp must be fully unrolled (register
@@ -15,5 +16,11 @@ for part in 1 2 3; do
 done
 hipcc $FLAGS -c alqp_ipm.hip -o build/alqp_ipm.o "$@" &
 pids+=($!)
+# register/LDS-resident interior-point kernel: one object per dtype
+hipcc $FLAGS -DALQP_G4_F64 -c alqp_ipm_g4.hip -o build/alqp_ipm_g4_f64.o "$@" &
+pids+=($!)
+hipcc $FLAGS -DALQP_G4_F32 -c alqp_ipm_g4.hip -o build/alqp_ipm_g4_f32.o "$@" &
+pids+=($!)
 for p in "${pids[@]}"; do wait "$p"; done
-hipcc --offload-arch=gfx950 -shared -fPIC build/alqp_part1.o build/alqp_part2.o build/alqp_part3.o build/alqp_ipm.o -o libmi_alqp.so
+hipcc --offload-arch=gfx950 -shared -fPIC build/alqp_part1.o build/alqp_part2.o build/alqp_part3.o build/alqp_ipm.o \
+  build/alqp_ipm_g4_f64.o build/alqp_ipm_g4_f32.o -o libmi_alqp.so

@@ -393,14 +393,19 @@ typedef struct AlqpIpmParams {
     int max_iter;    /* iterations of an ALQP_IPM_LOOP launch (reference: maxIter = 20, qp.py:203) */
     int iter0;       /* index of the (first) iteration this launch works on */
     double kkt_eps;  /* reference: 1e-7 (batch_LU.py:43) */
+    int variant;     /* ALQP_IPM_VARIANT_*: which kernel. Results agree to rounding; a per-call argument, no process state */
 } AlqpIpmParams;
+/* 0: automatic - the register/LDS-resident kernel (one QP per wavefront, iterate and directions in registers, F and
+ *    the Schur factor in LDS; HBM traffic = the inputs once + the best iterate when it improves) whenever the horizon
+ *    fits its register slots (T <= 20), else the size-generic kernel with automatic factor placement;
+ * 1 / 2: the size-generic kernel (vectors in the workspace) with the Schur factor in LDS / in the workspace;
+ * 3: the register/LDS-resident kernel, ALQP_E_UNSUPPORTED when the problem does not fit it. */
+#define ALQP_IPM_VARIANT_AUTO 0
+#define ALQP_IPM_VARIANT_GENERIC_LDS 1
+#define ALQP_IPM_VARIANT_GENERIC_WS 2
+#define ALQP_IPM_VARIANT_RESIDENT 3
 
 size_t alqp_ipm_workspace_bytes(const AlqpDims *dims, int is_f64);
-/* Tuning knob (process-wide): where the Schur factor of alqp_ipm_solve / _backward lives. 0 = auto (LDS while it
- * leaves >= 4 wavefronts per CU or the batch is below 2048; else the workspace, where more wavefronts per CU
- * hide its latency), 1 = always LDS when it fits,
- * 2 = always the workspace. Results are identical. */
-int alqp_ipm_set_factor_placement(int mode);
 int alqp_ipm_solve_f32(const AlqpDims *dims, const AlqpIpmParams *prm, const void *Cd, const void *c,
                        const void *F, const void *f, const void *x0, const void *u_hi, const void *u_lo,
                        long sC_t, long sC_b, long sF_t, long sF_b, long sf_t, long sf_b, void *workspace,
@@ -414,14 +419,14 @@ int alqp_ipm_solve_f64(const AlqpDims *dims, const AlqpIpmParams *prm, const voi
 /*
  * Backward of the QP layer (DenseQPFunction.backward, qp.py:238-252): one KKT solve, without
  * regularisation, at the returned lams / slacks: K (dx, ds, dlam, dnu) = -(gbar, 0, 0, 0).
- * The caller forms the reference's gradient formulas (:254-268) from dx, dlam, dnu.
+ * The caller forms the reference's gradient formulas (:254-268) from dx, dlam, dnu. variant: ALQP_IPM_VARIANT_*.
  */
 int alqp_ipm_backward_f32(const AlqpDims *dims, const void *Cd, const void *F, long sC_t, long sC_b, long sF_t,
                           long sF_b, const void *lams, const void *slacks, const void *gbar, void *workspace,
-                          size_t ws_bytes, void *dx, void *dlam, void *dnu, int *info, void *stream);
+                          size_t ws_bytes, void *dx, void *dlam, void *dnu, int *info, int variant, void *stream);
 int alqp_ipm_backward_f64(const AlqpDims *dims, const void *Cd, const void *F, long sC_t, long sC_b, long sF_t,
                           long sF_b, const void *lams, const void *slacks, const void *gbar, void *workspace,
-                          size_t ws_bytes, void *dx, void *dlam, void *dnu, int *info, void *stream);
+                          size_t ws_bytes, void *dx, void *dlam, void *dnu, int *info, int variant, void *stream);
 
 int alqp_abi_version(void);
 

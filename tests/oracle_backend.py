@@ -221,7 +221,7 @@ class OracleBackend:
         out["iters"] = o["iters"]
         return out
 
-    def ipm_backward(self, dims, Cd, F, lams, slacks, g):
+    def ipm_backward(self, dims, Cd, F, lams, slacks, g, variant=None):
         from oracle import ipm_py
         s = _sfx(g)
         tm = lambda a: np.ascontiguousarray(np.swapaxes(_n(a), 0, 1))

@@ -15,15 +15,13 @@ from deq_mpc_corl_amd.backend import default_backend
 B, T, nx, nu = [int(a) for a in (sys.argv[1:5] + [8192, 20, 13, 4][len(sys.argv) - 1:])][:4]
 be = default_backend()
 out = {"B": B, "T": T, "nx": nx, "nu": nu}
-modes = {"auto": 0, "lds": 1, "workspace": 2}
-for mode_name, mode in modes.items():
-  be.lib.alqp_ipm_set_factor_placement(mode)
+for mode_name in ("resident", "generic_lds", "generic_ws"):   # AlqpIpmParams.variant ("auto" = resident at these sizes)
   for dt, name in ((torch.float64, "f64"), (torch.float32, "f32")):
     name = f"{name}_{mode_name}"
     p = synthetic_problem(B, T, nx, nu, seed=0, dtype=dt, device="cuda:0")
     tm = lambda a: a.transpose(0, 1).contiguous()
     Cd, c, F, f = tm(p.Qd), tm(p.q), tm(p.F), tm(p.c)
-    run = lambda: be.ipm_solve((B, T, nx, nu), Cd, c, F, f, p.x0, p.u_hi, p.u_lo, exit_mode="fixed")
+    run = lambda: be.ipm_solve((B, T, nx, nu), Cd, c, F, f, p.x0, p.u_hi, p.u_lo, exit_mode="fixed", variant=mode_name)
     o = run()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
