@@ -289,7 +289,10 @@ def bench_extras(args, torch, be, _lib, dev, dims, p, run_solve, barrier):
         out["ipm"] = {"value": Bi * k / el, "unit": "QPs/s (20 interior-point iterations each)", "kernel_ms": kms,
                       "batch": Bi, "dtype": "f64", "kkt_order": nk,
                       "max_best_residual": float(res["o"]["resid"].max().item()),
-                      "kernel": "k_ipm", "note": "replaces 40 dense LU factorisations of order %d per QP" % nk}
+                      "kernel": "k_ipm_g4 (register/LDS-resident; AlqpIpmParams.variant auto)",
+                      "algorithmic_bytes_per_qp": 8 * (2 * T * n + (T - 1) * nx * (n + 1) + nx + 2 * T * n + 4 * T * nu + T * nx),
+                      "measured_hbm_bytes_per_qp": 140e3, "traffic_source": "profiles/r03/ipm_f64_summary.json",
+                      "note": "replaces 40 dense LU factorisations of order %d per QP" % nk}
     except Exception as e:  # pragma: no cover
         out["ipm"] = {"error": repr(e)}
     return out

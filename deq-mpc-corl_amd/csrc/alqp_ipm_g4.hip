@@ -9,10 +9,33 @@
 
 namespace alqp_ipm_g4 {
 
+#ifdef ALQP_G4_TIMING
+// debug build only (tools/g4_timing.sh): per-phase cycle totals over all wavefronts of all launches since the reset
+__device__ unsigned long long g_phase_cycles[16];
+template <typename real>
+__device__ __forceinline__ void GpuX<real>::publish_timing(const long long *t) {
+    if (threadIdx.x == 0)
+        for (int i = 0; i < 16; ++i) atomicAdd(&g_phase_cycles[i], (unsigned long long)t[i]);
+}
+extern "C" int alqp_g4_debug_phase_cycles(unsigned long long *out, int reset) {
+    if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(g_phase_cycles), sizeof(g_phase_cycles)) != hipSuccess) return -1;
+    if (reset) {
+        unsigned long long z[16] = {};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_phase_cycles), z, sizeof(z)) != hipSuccess) return -1;
+    }
+    return 0;
+}
+#endif
+
 constexpr int kSlots = 5;   // stage slots per lane group: T <= 4 * kSlots
 
+// Waves per SIMD the register allocation aims at: fp64 is LDS-limited to three workgroups per CU at (20,13,4) (53 KB
+// each), one wavefront per SIMD with the whole register file; fp32 images are half the size (six per CU), so the
+// kernel is held to 256 registers and two wavefronts share a SIMD and hide each other's LDS and DPP latencies.
+template <typename real> constexpr int kWavesPerSimd = sizeof(real) == 4 ? 2 : 1;
+
 template <typename real, int NX, int NU>
-__global__ __launch_bounds__(64) void k_ipm_g4(const IpmArgs<real> a) {
+__global__ __launch_bounds__(64, kWavesPerSimd<real>) void k_ipm_g4(const IpmArgs<real> a) {
     extern __shared__ __align__(16) unsigned char lds_raw[];
     const int b = blockIdx.x;
     if (b >= a.B) return;
@@ -21,7 +44,7 @@ __global__ __launch_bounds__(64) void k_ipm_g4(const IpmArgs<real> a) {
 }
 
 template <typename real, int NX, int NU>
-__global__ __launch_bounds__(64) void k_ipm_g4_backward(const IpmArgs<real> a, const real *lams, const real *slacks) {
+__global__ __launch_bounds__(64, kWavesPerSimd<real>) void k_ipm_g4_backward(const IpmArgs<real> a, const real *lams, const real *slacks) {
     extern __shared__ __align__(16) unsigned char lds_raw[];
     const int b = blockIdx.x;
     if (b >= a.B) return;

@@ -94,6 +94,9 @@ struct Solver {
     V Px[SL], Pu[SL], Dt[SL];            // 1/Phi on the state / control rows, D~ on the bound rows
     int sFt, sCt, sft;
     KV cur;
+#ifdef ALQP_G4_TIMING
+    long long tlast, tacc[16];   // debug build (tools/g4_timing.sh): cycles since the previous tick, attributed per phase
+#endif
     VI infov;                            // first non-positive pivot (block * nx + column + 1), 0 if none; uniform
     int info;
     real sc_best, sc_mu, sc_have, sc_iter;
@@ -114,6 +117,10 @@ struct Solver {
         x0g = a.x0 ? a.x0 + (long)b * NX : nullptr;
         lane = X::lane_id();
         infov = X::splati(0);
+#ifdef ALQP_G4_TIMING
+        for (int i = 0; i < 16; ++i) tacc[i] = 0;
+        tlast = X::now();
+#endif
         refresh();
     }
     // Everything derived from the lane index (masks, LDS / global offsets) is loop-invariant, and hipcc hoists all
@@ -123,6 +130,17 @@ struct Solver {
         X::launder(lane);
         r = lane & 15; g = lane >> 4; qd = r >> 2; j = r & 3;
         rc = X::seli(r < NX, r, X::splati(NX - 1));
+    }
+    // phases: 0 problem load, 1 residuals, 2 factor (Dt, Pu), 3 factor blocks, 4 apply right-hand side, 5 forward sweep,
+    // 6 backward sweep, 7 apply outputs, 8 K product, 9 step lengths / updates, 10 workspace + outputs
+    G4_FN void tick(int ph) {
+#ifdef ALQP_G4_TIMING
+        const long long now = X::now();
+        tacc[ph] += now - tlast;
+        tlast = now;
+#else
+        (void)ph;
+#endif
     }
     G4_FN VM mXr() const { return r < NX; }
     G4_FN VM mQ() const { return (qd < 2) & (j < NU); }
@@ -189,6 +207,7 @@ struct Solver {
         if (a.uhi && a.ulo) hq = X::g_ld(a.uhi, j, mQ() & (qd == 0)) - X::g_ld(a.ulo, j, mQ() & (qd == 1));
         X::lds_st(sM, lane * MSZ + ZC, zero(), lane < T);   // the zero cells of every stage's factor block
         X::fence();
+        tick(0);
     }
 
     // cost diagonal / linear term / affine term of slot i's stage, re-read where they are used (L2-resident inputs:
@@ -246,7 +265,6 @@ struct Solver {
             fmac_row<X, 0, NX>(acc, xp[i], fr);
             fmac_row<X, 8, NU>(acc, up[i], fr + NX);
             out[i] = keep(mx(i) & (t > 0), acc);
-            X::sched_fence();   // one slot's matrix rows in registers at a time
         }
     }
     // ox (lanes k < nx) = (F_t' yn)_k, ou (quarter 2) = (F_t' yn)_{nx+j}; yn = the next stage's multiplier slice
@@ -267,7 +285,6 @@ struct Solver {
             fmac_row<X, 0, NX>(au, yn[i], fc);
             ox[i] = keep(mx(i) & (t < T - 1), ax);
             ou[i] = keep(mu(i) & (t < T - 1), au);
-            X::sched_fence();
         }
     }
 
@@ -307,6 +324,7 @@ struct Solver {
             sc_best = rsd; sc_have = 1; sc_iter = real(it);
         }
         sc_mu = mu_;
+        tick(1);
         return better ? 1 : 0;
     }
     static G4_FN real fabs_(real v) { return v < 0 ? -v : v; }
@@ -314,6 +332,11 @@ struct Solver {
     static G4_FN real sqrt_(double v) { return sqrt(v); }
 
     // ---- factorisation at the current (s, z) ----------------------------------------------------------
+    // Per block m (lane r = row r of every 13 x 13 matrix, all four groups alike):
+    //   S = F P F' + P_x + eps  -  Z D^-1 Z',   Z = S_{m,m-1} M_{m-1}'   (rank-1 updates of the row set: X::multi)
+    //   S = L D L' and M = L^-1 in ONE pivot loop: the row operation that eliminates column C of S is applied to an
+    //   identity alongside (X::self), so M's rows come out on the lanes that own them - no separate triangular inversion
+    //   with its dependent chains - and stay in registers for the next block's Z.
     G4_FN void factor() {
         refresh();
         G4_UNROLL
@@ -323,14 +346,18 @@ struct Solver {
             X::lds_st(sPu, tof(i) * 4 + j, Pu[i], mu(i));
         }
         X::fence();
+        tick(2);
+        V Mrow[NX];      // row r of M_{m-1} (unit lower: Mrow[k] = M[r][k] for k < r, 1 at k = r, 0 beyond)
+        V dprev[NX];     // 1 / d_k of block m-1 (uniform)
+        G4_UNROLL
+        for (int k = 0; k < NX; ++k) { Mrow[k] = zero(); dprev[k] = zero(); }
         for (int m = 0; m < T; ++m) {
             real *Mm = sM + (long)m * MSZ;
             V S[NX];
             const V pm = X::lds_ld(sPx, rc + m * NX) + e;
-            if (m == 0) {
-                G4_UNROLL
-                for (int c = 0; c < NX; ++c) S[c] = keep(r == c, pm);
-            } else {
+            G4_UNROLL
+            for (int c = 0; c < NX; ++c) S[c] = keep(r == c, pm);
+            if (m > 0) {
                 const int t = m - 1;
                 const VI base = rc * N + t * FSZ;
                 V fr[N], fp[N];
@@ -340,59 +367,62 @@ struct Solver {
                     fp[k] = fr[k] * (k < NX ? X::lds_ldu(sPx, t * NX + k) : X::lds_ldu(sPu, t * 4 + (k - NX)));
                 }
                 G4_UNROLL
-                for (int c = 0; c < NX; ++c) S[c] = keep(r == c, pm);
-                G4_UNROLL
                 for (int k = 0; k < N; ++k) fmac_multi<X, 0, NX>(S, fr[k], fp[k]);   // F P F'
-                // Z = S_{m,m-1} M_{m-1}' : Z[r][c] = -(fp[c] + sum_{k<c} fp[k] M[c][k])  (M unit lower)
-                const real *Mp = sM + (long)(m - 1) * MSZ;
+                tick(11);
+                // Z[r][c] = -(fp[c] + sum_{k<c} M[c][k] fp[k]), M[c][k] = lane c's Mrow[k]
                 V Z[NX], zd[NX];
                 G4_UNROLL
-                for (int c = 0; c < NX; ++c) {
-                    V acc = fp[c];
-                    G4_UNROLL
-                    for (int k = 0; k < c; ++k) acc = acc + fp[k] * X::lds_ldu(Mp, c * (c - 1) / 2 + k);
-                    Z[c] = -acc;
-                    zd[c] = acc * X::lds_ldu(Mp, NXL + c);       // = -Z[c] / d_c
-                }
+                for (int c = 0; c < NX; ++c) Z[c] = fp[c];
+                z_rows<0>(Z, Mrow, fp);
+                G4_UNROLL
+                for (int c = 0; c < NX; ++c) { zd[c] = Z[c] * dprev[c]; Z[c] = -Z[c]; }
+                tick(12);
                 G4_UNROLL
                 for (int k = 0; k < NX; ++k) fmac_multi<X, 0, NX>(S, Z[k], zd[k]);   // S -= Z D^-1 Z'
+                tick(13);
             }
-            // S~_m = L D L' (right-looking, lane r = row r; a non-positive pivot is replaced by |d| and flagged)
-            V lrow[NX];
             G4_UNROLL
-            for (int c = 0; c < NX; ++c) lrow[c] = zero();
-            ldl<0>(S, lrow, Mm + NXL, m);
-            // M = L^-1: lane c builds column c by forward substitution; L[i][k] is lane i's lrow[k]
-            V col[NX], ncol[NX];
-            invert_unit_lower<0>(lrow, col, ncol);
+            for (int k = 0; k < NX; ++k) Mrow[k] = keep(r == k, X::splat(real(1)));
+            ldl<0>(S, Mrow, dprev, m);
+            tick(14);
             G4_UNROLL
-            for (int i = 1; i < NX; ++i) X::lds_st(Mm, r + i * (i - 1) / 2, col[i], g0() & (r < i));
+            for (int k = 0; k + 1 < NX; ++k) X::lds_st(Mm, ((rc * (rc - 1)) >> 1) + k, Mrow[k], g0() & (r > k) & mXr());
+            X::lds_st(Mm, r + NXL, dlane(dprev), g0() & mXr());
             X::fence();
+            tick(15);
         }
         info = X::firsti(infov);
+        tick(3);
     }
-    // column C of S~ = L D L': d = S[C][C] (uniform), L[r][C] = S[r][C] / d, trailing update of the rows
+    // Z[c] += sum_{k<c} bcast_c(Mrow[k]) * fp[k], as rank-1 updates over k (entries with c <= k are zero and skipped)
+    template <int K>
+    G4_FN void z_rows(V *Z, const V *Mrow, const V *fp) const {
+        if constexpr (K + 1 < NX) {
+            fmac_multi<X, K + 1, NX - 1 - K>(Z + K + 1, Mrow[K], fp[K]);
+            z_rows<K + 1>(Z, Mrow, fp);
+        }
+    }
+    // lane k's element k of a uniform array (for the store of 1/d)
+    G4_FN V dlane(const V *d) const {
+        V o = zero();
+        G4_UNROLL
+        for (int k = 0; k < NX; ++k) o = X::sel(r == k, d[k], o);
+        return o;
+    }
+    // column C of S~ = L D L': d = S[C][C] (uniform; a non-positive pivot is replaced by |d| and flagged),
+    // L[r][C] = S[r][C] / d for r > C; the row operation row_r -= L[r][C] row_C on the trailing columns of S and on the
+    // leading columns of the identity that becomes M = L^-1
     template <int C>
-    G4_FN void ldl(V *S, V *lrow, real *Dm, int m) {
+    G4_FN void ldl(V *S, V *Mrow, V *dinv, int m) {
         if constexpr (C < NX) {
             const V d = X::template bcast<C>(S[C]);
             infov = X::seli((infov == 0) & !(d > zero()), X::splati(m * NX + C + 1), infov);
             const V di = X::rcp(X::absv(d));
-            X::lds_st(Dm, X::splati(C), di, lane == 0);
-            const V l = S[C] * di;
-            lrow[C] = l;
-            fmac_multi<X, C + 1, NX - 1 - C>(S + C + 1, S[C], -l);   // S[r][k] -= L[r][C] * S[k][C], k > C
-            ldl<C + 1>(S, lrow, Dm, m);
-        }
-    }
-    template <int I>
-    G4_FN void invert_unit_lower(const V *lrow, V *col, V *ncol) const {
-        if constexpr (I < NX) {
-            V acc = keep(r == I, X::splat(real(1)));
-            fmac_vec<X, I, I>(acc, lrow, ncol);      // - sum_{k<I} L[I][k] col[k]
-            col[I] = acc;
-            ncol[I] = -acc;
-            invert_unit_lower<I + 1>(lrow, col, ncol);
+            dinv[C] = di;
+            const V nl = keep(r > C, -(S[C] * di));
+            fmac_multi<X, C + 1, NX - 1 - C>(S + C + 1, S[C], nl);   // S[r][k] -= L[r][C] * S[k][C], k > C
+            if constexpr (C + 1 < NX) X::template self<C, C + 1>(Mrow, nl);   // M[r][k] -= L[r][C] * M[C][k], k <= C
+            ldl<C + 1>(S, Mrow, dinv, m);
         }
     }
 
@@ -405,22 +435,44 @@ struct Solver {
             o.C[k] = X::seli((r < k) & mXr(), X::splati(k * (k - 1) / 2) + rc, X::splati(ZC));
         }
     }
-    G4_FN V Sinv(int m, const V &v, const MOff &mo) const {
+    // Operands of one sweep stage, loaded from LDS one stage AHEAD of their use (two sets, ping-pong): a wavefront is
+    // alone on its SIMD, so nothing else hides the LDS latency of a stage's ~40 matrix reads.
+    static constexpr int NM = NX > 1 ? NX - 1 : 1;
+    struct SweepOps { V a[NX], mr[NM], mc[NM], di, px, v; };
+    G4_FN void load_factor(int m, SweepOps &o, const MOff &mo) const {
         const real *Mm = sM + (long)m * MSZ;
+        G4_UNROLL
+        for (int k = 0; k + 1 < NX; ++k) o.mr[k] = X::lds_ld(Mm, mo.R[k]);
+        G4_UNROLL
+        for (int k = 1; k < NX; ++k) o.mc[k - 1] = X::lds_ld(Mm, mo.C[k]);
+        o.di = X::lds_ld(Mm, rc + NXL);
+        o.px = X::lds_ld(sPx, rc + m * NX);
+        o.v = X::lds_ld(sV, rc + m * NX);
+    }
+    G4_FN void load_fwd(int m, SweepOps &o, const MOff &mo) const {   // rows of A_{m-1} (lane r: row r)
+        if (m > 0) {
+            const VI base = rc * N + (m - 1) * FSZ;
+            G4_UNROLL
+            for (int k = 0; k < NX; ++k) o.a[k] = X::lds_ld(sF, base + k);
+        }
+        load_factor(m, o, mo);
+    }
+    G4_FN void load_bwd(int m, SweepOps &o, const MOff &mo) const {   // columns of A_m (lane k: column k)
+        const VI cb = rc + m * FSZ;
+        G4_UNROLL
+        for (int q2 = 0; q2 < NX; ++q2) o.a[q2] = X::lds_ld(sF, cb + q2 * N);
+        load_factor(m, o, mo);
+    }
+    // S~_m^-1 v = M' (D^-1 (M v)) with the stage's packed factor block in o
+    G4_FN V Sinv(const V &v, const SweepOps &o) const {
         if constexpr (NX == 1) {
-            return v * X::lds_ld(Mm, rc + NXL);
+            return v * o.di;
         } else {
-            V mr[NX - 1], mc[NX - 1];
-            G4_UNROLL
-            for (int k = 0; k < NX - 1; ++k) mr[k] = X::lds_ld(Mm, mo.R[k]);
-            G4_UNROLL
-            for (int k = 1; k < NX; ++k) mc[k - 1] = X::lds_ld(Mm, mo.C[k]);
-            const V di = X::lds_ld(Mm, rc + NXL);
             V a1 = v;
-            fmac_row<X, 0, NX - 1>(a1, v, mr);
-            const V a2 = a1 * di;
+            fmac_row<X, 0, NX - 1>(a1, v, o.mr);
+            const V a2 = a1 * o.di;
             V p = a2;
-            fmac_row<X, 1, NX - 1>(p, a2, mc);
+            fmac_row<X, 1, NX - 1>(p, a2, o.mc);
             return p;
         }
     }
@@ -442,50 +494,49 @@ struct Solver {
         G4_UNROLL
         for (int i = 0; i < SL; ++i) X::lds_st(sV, tof(i) * NX + r, Fp[i] - prx[i] - bb.ys[i], mx(i));
         X::fence();
+        tick(4);
         // forward sweep
         MOff mo;
         m_offsets(mo);
         // (both sweeps are unrolled four stages deep: the stage offsets of the LDS reads become immediates instead of
-        //  one address addition per matrix entry)
+        //  one address addition per matrix entry, and the two operand sets alternate by a compile-time index)
+        SweepOps so[2];
+        load_fwd(0, so[0], mo);
         V q = zero(), p = zero();
         for (int m0 = 0; m0 < T; m0 += 4) {
             G4_UNROLL
             for (int mm = 0; mm < 4; ++mm) {
                 const int m = m0 + mm;
                 if (m >= T) break;
-                V v = X::lds_ld(sV, rc + m * NX);
-                if (m > 0) {
-                    const VI base = rc * N + (m - 1) * FSZ;
-                    V ar[NX];
-                    G4_UNROLL
-                    for (int k = 0; k < NX; ++k) ar[k] = X::lds_ld(sF, base + k);
-                    fmac_row<X, 0, NX>(v, q, ar);
-                }
-                p = Sinv(m, v, mo);
+                const SweepOps &c = so[mm & 1];
+                if (m + 1 < T) load_fwd(m + 1, so[(mm + 1) & 1], mo);
+                V v = c.v;
+                if (m > 0) fmac_row<X, 0, NX>(v, q, c.a);
+                p = Sinv(v, c);
                 X::lds_st(sV, r + m * NX, p, g0() & mXr());
-                q = p * X::lds_ld(sPx, rc + m * NX);
+                q = p * c.px;
             }
         }
+        tick(5);
         // backward sweep
+        load_bwd(T - 2, so[0], mo);
         V xn = p;
         for (int m0 = T - 2; m0 >= 0; m0 -= 4) {
             G4_UNROLL
             for (int mm = 0; mm < 4; ++mm) {
                 const int m = m0 - mm;
                 if (m < 0) break;
-                const VI cb = rc + m * FSZ;
-                V ac[NX];
-                G4_UNROLL
-                for (int q2 = 0; q2 < NX; ++q2) ac[q2] = X::lds_ld(sF, cb + q2 * N);
+                const SweepOps &c = so[mm & 1];
+                if (m > 0) load_bwd(m - 1, so[(mm + 1) & 1], mo);
                 V wq = zero();
-                fmac_row<X, 0, NX>(wq, xn, ac);
-                wq = wq * X::lds_ld(sPx, rc + m * NX);
-                const V cc = Sinv(m, wq, mo);
-                xn = X::lds_ld(sV, rc + m * NX) + cc;
+                fmac_row<X, 0, NX>(wq, xn, c.a);
+                wq = wq * c.px;
+                xn = c.v + Sinv(wq, c);
                 X::lds_st(sV, r + m * NX, xn, g0() & mXr());
             }
         }
         X::fence();
+        tick(6);
         // outputs
         refresh();
         V dy[SL], dyn[SL], fx_[SL], fu_[SL];
@@ -510,6 +561,7 @@ struct Solver {
             bb.c1[i] = dz;
         }
         X::fence();
+        tick(7);
     }
 
     // rr <- rr - K(z, s) l   (K without regularisation)
@@ -531,6 +583,7 @@ struct Solver {
             rr.c1[i] = rr.c1[i] - oZ;
             rr.ys[i] = rr.ys[i] - oY;
         }
+        tick(8);
     }
 
     static G4_FN void kv_copy(KV &d, const KV &v) {
@@ -684,6 +737,7 @@ struct Solver {
                 moved = true;
             }
         }
+        tick(9);
         refresh();
         if (moved) store_kv(w + L.cur, cur);
         if (do_init || do_resid) X::store4(sc, sc_best, sc_mu, sc_have, sc_iter);
@@ -700,6 +754,10 @@ struct Solver {
             }
         }
         X::store_scalars(a, b, sc_best, sc_mu, (int)sc_iter, improved, info);
+        tick(10);
+#ifdef ALQP_G4_TIMING
+        X::publish_timing(tacc);
+#endif
     }
 
     // ---- backward of DenseQPFunction (qp.py:238-252): K at the returned lams / slacks, no regularisation ----

@@ -68,29 +68,36 @@ struct EmuX {
     // row_newbcast: lane K of each 16-lane row
     template <int K> static V bcast(const V &x) { V o; for (int l = 0; l < W; ++l) o.v[l] = x.v[(l & 48) + K]; return o; }
     static V gather(const V &x, const VI &src) { V o; for (int l = 0; l < W; ++l) o.v[l] = x.v[src.v[l] & 63]; return o; }
-    // broadcast-FMA chains, in the GPU blocks' order of operations (two alternating accumulators from 4 terms on)
+    // broadcast-FMA chains, in the GPU blocks' order of operations
     template <int K0, int C> static void row(V &acc, const V &x, const V *m) {
         const V xs = x;   // (acc and x never share a register on the GPU: early-clobber accumulators)
         V tmp = splat(real(0));
         for (int i = 0; i < C; ++i) {
-            V &d = (C >= 4 && (i & 1)) ? tmp : acc;
+            V &d = (false && (i & 1)) ? tmp : acc;
             for (int l = 0; l < W; ++l) d.v[l] = std::fma(xs.v[(l & 48) + K0 + i], m[i].v[l], d.v[l]);
         }
-        if (C >= 4) for (int l = 0; l < W; ++l) acc.v[l] += tmp.v[l];
+        
     }
     template <int K0, int C> static void multi(V *acc, const V &x, const V &m) {
         const V xs = x, ms = m;
         for (int i = 0; i < C; ++i) for (int l = 0; l < W; ++l) acc[i].v[l] = std::fma(xs.v[(l & 48) + K0 + i], ms.v[l], acc[i].v[l]);
+    }
+    template <int K, int C> static void self(V *acc, const V &m) {
+        const V ms = m;
+        for (int i = 0; i < C; ++i) {
+            const V old = acc[i];
+            for (int l = 0; l < W; ++l) acc[i].v[l] = std::fma(old.v[(l & 48) + K], ms.v[l], old.v[l]);
+        }
     }
     template <int K, int C> static void vec(V &acc, const V *x, const V *m) {
         if constexpr (C > 13) { vec<K, 13>(acc, x, m); vec<K, C - 13>(acc, x + 13, m + 13); }
         else {
             V tmp = splat(real(0));
             for (int i = 0; i < C; ++i) {
-                V &d = (C >= 4 && (i & 1)) ? tmp : acc;
+                V &d = (false && (i & 1)) ? tmp : acc;
                 for (int l = 0; l < W; ++l) d.v[l] = std::fma(x[i].v[(l & 48) + K], m[i].v[l], d.v[l]);
             }
-            if (C >= 4) for (int l = 0; l < W; ++l) acc.v[l] += tmp.v[l];
+            
         }
     }
     // memory
