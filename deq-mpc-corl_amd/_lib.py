@@ -24,7 +24,7 @@ class AlqpParams(C.Structure):
     _fields_ = [("al_iter", C.c_int), ("max_newton", C.c_int), ("n_ls", C.c_int),
                 ("flags", C.c_int), ("rho_scale", C.c_double), ("variant", C.c_int),
                 ("skip_flag", C.c_void_p), ("exit_tol", C.c_double), ("newton_counts", C.c_void_p),
-                ("exit_scratch", C.c_void_p)]
+                ("exit_scratch", C.c_void_p), ("quad_stagger", C.c_int)]
 
 
 class AlqpTrace(C.Structure):
@@ -103,7 +103,6 @@ _PLAIN = {
     "alqp_exit_test": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_void_p]),
     "alqp_workspace_bytes_nonlin": (C.c_size_t, [C.POINTER(AlqpDims), C.c_int]),
     "alqp_ipm_workspace_bytes": (C.c_size_t, [C.POINTER(AlqpDims), C.c_int]),
-    "alqp_set_quad_stagger": (C.c_int, [C.c_int]),
 }
 
 EXPORTED_SYMBOLS = sorted([f"{n}_{s}" for n in _SIGS for s in ("f32", "f64")] + list(_PLAIN))

@@ -65,10 +65,14 @@ class HipBackend:
         if os.environ.get("ALQP_QUAD_STAGGER") is not None:   # -1 auto (default), 0 off, > 0 units of ~1024 clocks
             self.set_quad_stagger(int(os.environ["ALQP_QUAD_STAGGER"]))
 
+    quad_stagger = -1   # -1 automatic, 0 off, > 0 explicit units of ~1024 clocks (passed per call in AlqpParams.quad_stagger)
+
     def set_quad_stagger(self, mode):
-        """Start offset between the four wavefronts of a CU in the quad solve (alqp_set_quad_stagger, include/mi_alqp.h):
-        -1 automatic, 0 off, > 0 explicit. Returns the previous mode. Timing only - results do not depend on it."""
-        return int(self.lib.alqp_set_quad_stagger(int(mode)))
+        """Start offset between the four wavefronts of a CU in the quad solve (AlqpParams.quad_stagger, include/mi_alqp.h):
+        -1 automatic, 0 off, > 0 explicit. Returns the previous mode. Timing only - results do not depend on it.
+        State of THIS backend object; the library keeps none."""
+        prev, self.quad_stagger = self.quad_stagger, (-1 if int(mode) < 0 else int(mode))
+        return prev
 
     def workspace_bytes(self, B, T, nx, nu, dtype):
         d = _lib.AlqpDims(B, T, nx, nu)
@@ -134,6 +138,7 @@ class HipBackend:
         self.last_variant = "quad" if vnum == 2 else "team"
         skp = _ptr(skip, "skip", torch.float64, True)
         p = _lib.AlqpParams(al_iter, max_newton, n_ls, flags | _DEBUG_FLAGS, rho_scale, vnum, skp.value if skp is not None else None)
+        p.quad_stagger = {-1: 0, 0: -1}.get(self.quad_stagger, self.quad_stagger)   # ABI: 0 automatic, < 0 off
         if newton_counts is not None:
             self._exit_in_kernel(p, B, z.device, newton_counts, exit_tol)
         tr = None

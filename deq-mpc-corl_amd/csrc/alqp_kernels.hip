@@ -55,22 +55,32 @@ __device__ inline double grid_sum_ordered(double block_val, double *scratch, int
     // Co-residency of the grid is guaranteed by the cooperative launch, so the spin cannot starve anyone.
     double *p = scratch + 1 + (size_t)(phase & 1) * gridDim.x;
     unsigned *cnt = reinterpret_cast<unsigned *>(scratch);
+    double *timed_out = scratch + 1 + 2 * (size_t)gridDim.x;
     if (threadIdx.x == 0) {
+        // Ordering: the partial is an agent-scope store, the arrival an agent-scope RELEASE add (the partial is visible to
+        // whoever observes the count), the consumer side one ACQUIRE load after the spin (its later loads of the partials
+        // cannot be satisfied from before the count was seen). The spin itself polls relaxed (an acquire per poll is 2-3x
+        // slower per hop, MI355X_MICROARCH.md "Invalid forms").
         __hip_atomic_store(p + blockIdx.x, block_val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __builtin_amdgcn_s_waitcnt(0);   // the partial has reached the coherence point before the arrival is counted
-        __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
         const unsigned target = (unsigned)(phase + 1) * gridDim.x;
-        // bounded spin (~1 s): every wavefront reaches an exit even if an arrival never shows up; the caller then sees NaN,
-        // never takes the early exit and reports -1 Newton steps, which the host turns into an error
-        long spins = 0;
-        while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target && spins < (1L << 23)) {
-            __builtin_amdgcn_s_sleep(2);
-            ++spins;
+        // Bounded spin: ~1 s of wall clock (s_memrealtime ticks at 100 MHz), and none at all once a previous phase has
+        // timed out - every wavefront reaches an exit even if an arrival never shows up; the caller then sees NaN, never
+        // takes the early exit and reports -1 Newton steps, which the host turns into an error.
+        if (__hip_atomic_load(timed_out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0.0) {
+            const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+            bool late = false;
+            while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+                __builtin_amdgcn_s_sleep(2);
+                if (__builtin_amdgcn_s_memrealtime() - t0 > 100000000ull ||
+                    __hip_atomic_load(timed_out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0.0) { late = true; break; }
+            }
+            if (late) __hip_atomic_store(timed_out, 1.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            else (void)__hip_atomic_load(cnt, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
         }
-        if (spins >= (1L << 23)) __hip_atomic_store(scratch + 1 + 2 * (size_t)gridDim.x, 1.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     __builtin_amdgcn_s_barrier();   // one wavefront per workgroup: re-converges the lanes behind lane 0's spin
-    if (__hip_atomic_load(scratch + 1 + 2 * (size_t)gridDim.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0.0) {
+    if (__hip_atomic_load(timed_out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0.0) {
         ++phase;
         return __builtin_nan("");
     }
@@ -934,9 +944,18 @@ template <typename Fn, typename A0, typename... Rest>
 int launch_maybe_coop(Fn fn, unsigned grid, size_t lds, hipStream_t stream, A0 a0, Rest... rest) {
     if (flags_of(a0) & ALQP_EXIT_IN_KERNEL) {
         void *argv[] = {(void *)&a0, (void *)&rest...};
+        // Any refusal of the cooperative launch (grid too large, cooperative launches not supported by the device or the
+        // queue, ...) is ALQP_E_COOP: the caller then takes the launch-per-step route, which needs no co-residency.
+        static int coop_ok = -1;
+        if (coop_ok < 0) {
+            int dev = 0, v = 0;
+            coop_ok = (hipGetDevice(&dev) == hipSuccess &&
+                       hipDeviceGetAttribute(&v, hipDeviceAttributeCooperativeLaunch, dev) == hipSuccess && v) ? 1 : 0;
+        }
+        if (!coop_ok) return ALQP_E_COOP;
         hipError_t e = hipLaunchCooperativeKernel(reinterpret_cast<const void *>(fn), dim3(grid), dim3(64), argv, (unsigned)lds, stream);
-        if (e == hipErrorCooperativeLaunchTooLarge) { (void)hipGetLastError(); return ALQP_E_COOP; }
-        return e == hipSuccess ? 0 : ALQP_E_LAUNCH;
+        if (e != hipSuccess) { (void)hipGetLastError(); return ALQP_E_COOP; }
+        return 0;
     }
     hipLaunchKernelGGL(fn, dim3(grid), dim3(64), lds, stream, a0, rest...);
     return hipGetLastError() == hipSuccess ? 0 : ALQP_E_LAUNCH;
@@ -1129,10 +1148,11 @@ static int qpw_query(int nx, int nu) {
 static bool dims_ok(const AlqpDims *d) { return d && d->B > 0 && d->T >= 2 && d->nx > 0 && d->nu > 0; }
 
 // ---- start offset between the wavefronts of a CU for the quad solve (SolveArgs::stagger) -------------------
-// g_stagger_mode: -1 auto, 0 off, > 0 explicit units of ~1024 clocks (alqp_set_quad_stagger)
-static int g_stagger_mode = -1;
-static int quad_stagger(int B, int T, int nx, int nu, int newton_steps, bool f64) {
-    if (g_stagger_mode >= 0) return g_stagger_mode;
+// mode = AlqpParams.quad_stagger: 0 automatic, < 0 off, > 0 explicit units of ~1024 clocks (a per-call argument: the library
+// keeps no process state)
+static int quad_stagger(int mode, int B, int T, int nx, int nu, int newton_steps, bool f64) {
+    if (mode < 0) return 0;
+    if (mode > 0) return mode;
     static int n_simd = 0;
     if (n_simd == 0) {
         int dev = 0, cus = 0;
@@ -1178,7 +1198,7 @@ int solve_lin_impl(const AlqpDims *dims, const AlqpParams *prm, const void *Qd, 
     a.z = (real *)z; a.lam = (real *)lam; a.rho = (real *)rho; a.phi = (real *)phi;
     a.rnorm2 = (real *)rnorm2; a.info = info; a.status = status; a.factor = (real *)factor_out;
     a.skip = prm->skip_flag;
-    a.stagger = quad_stagger(dims->B, dims->T, dims->nx, dims->nu, prm->al_iter * prm->max_newton, sizeof(real) == 8);
+    a.stagger = quad_stagger(prm->quad_stagger, dims->B, dims->T, dims->nx, dims->nu, prm->al_iter * prm->max_newton, sizeof(real) == 8);
     if (prm->flags & ALQP_EXIT_IN_KERNEL) {
         if (!prm->exit_scratch || trace || prm->skip_flag) return ALQP_E_BADARG;
         a.exit_tol = prm->exit_tol; a.newton_counts = prm->newton_counts; a.exit_scratch = prm->exit_scratch;
@@ -1615,12 +1635,6 @@ __global__ void k_exit_test(const double *sumsq, double *ctl, int mode, double t
 extern "C" {
 
 int alqp_abi_version(void) { return 10; }
-
-int alqp_set_quad_stagger(int mode) {
-    const int prev = alqp::g_stagger_mode;
-    alqp::g_stagger_mode = mode < 0 ? -1 : mode;
-    return prev;
-}
 
 int alqp_dyn_pendulum1l_f32(long K, const void *x, const void *u, double h, const void *h_pt, void *xnext, void *F, void *stream) {
     return alqp::dyn_pendulum1l_impl<float>(K, x, u, h, h_pt, xnext, F, stream);

@@ -290,9 +290,15 @@ class MPC(Module):
         state-estimator variant's set without initial-state rows; the plain MPC has none."""
         return {"obs": "state_estimator"} if self.state_estimator else {}
 
+    def _has_extra_rows(self):
+        """True when the constraint-row set differs from the plain MPC's (obstacle rows, state estimator): a predicate
+        that moves no tensor (the former `bool(_obs_kwargs(dtype, "cpu"))` copied the obstacle centres to the host and
+        synchronised on every solve)."""
+        return bool(self.state_estimator)
+
     def _as_lindx(self, dx, B):
         """(F[B,T-1,nx,n], c[B,T-1,nx]) if `dx` carries affine data, else None."""
-        if self._obs_kwargs(self.dtype, "cpu"):
+        if self._has_extra_rows():
             return None   # obstacle rows exist only in the nonlinear-caller building blocks
         F = getattr(dx, "F", None)
         c = getattr(dx, "f", None)
@@ -552,7 +558,7 @@ class MPC(Module):
             # autograd rejects it, so the reference cannot differentiate this route. Same error type.
             raise RuntimeError("MPC: the linearize_once streaming route is not differentiable (the reference's "
                                "al_utils_lin.NewtonAL.backward returns an incorrect number of gradients)")
-        has_obs = bool(self._obs_kwargs(dt, dev))
+        has_obs = self._has_extra_rows()
         use_qws = need_grad and hasattr(be, "backward_ws") and B >= getattr(be, "QUAD_MIN_BATCH", 0) and (
             lin is not None or not has_obs) and not (bool(self.linearize_once) and st.stream_mode)
         if use_qws:

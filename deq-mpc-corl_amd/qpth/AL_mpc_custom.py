@@ -60,10 +60,15 @@ class Obstacle_MPC(MPC):
         last = self._nearest(x[:, -1:])
         self.obstacles = (torch.cat([self.obstacles[0][:, 1:], last.to(self.obstacles[0])], dim=1), self.obstacle_radius)
 
+    def _has_extra_rows(self):
+        return True
+
     def _obs_kwargs(self, dtype, device):
         if self.obstacles is None:
+            # (the reference dies with AttributeError here: its nearest-sphere table is built by reinitialize, :104-109.
+            #  Passing "no obstacles" on would select the plain kernels, whose multiplier stride is M, on a [B, M + 4T] lamda)
             if self.obstacle_positions is None:
                 raise RuntimeError("Obstacle_MPC: no obstacle positions (pass env=... with obstacle_positions)")
-            return {"obs": None}   # truthy marker before reinitialize(): the solve itself needs the centres
+            raise RuntimeError("Obstacle_MPC: call reinitialize() before the first solve (it selects the nearest spheres)")
         pos, radius = self.obstacles
         return {"obs": (pos.detach().to(device=device, dtype=dtype).contiguous(), float(radius))}

@@ -193,6 +193,14 @@ class MPC(Module):
             torch.distributed.all_reduce(ok, op=torch.distributed.ReduceOp.MIN, group=self.process_group)
         return bool(ok.item())
 
+    def _global_norm(self, v):
+        """`v.norm()` over the whole batch: the squared norm is summed over the ranks of a sharded batch (like
+        AL_mpc.MPC._global_norm), so that every rank takes the same decision on it."""
+        sq = (v.to(torch.float64) ** 2).sum().reshape(1)
+        if self._sharded():
+            torch.distributed.all_reduce(sq, op=torch.distributed.ReduceOp.SUM, group=self.process_group)
+        return float(sq.sqrt().item())
+
     def _bound(self, v, like):
         v = torch.as_tensor(v, dtype=like.dtype, device=like.device)
         if v.dim() > 1:
@@ -316,12 +324,15 @@ class MPC(Module):
         (:347, 371), so only the step-norm test can end the loop early."""
         best = None
         B = x.shape[1]
+        self.last_sqp_iters = 0
         with torch.no_grad():
             for _ in range(self.qp_iter):
                 u_prev = u.clone()
                 delta_x, delta_u, _ = self.single_qp(x, u, dx, dx_jac, x0, cost)
                 x, u, alpha, cost_total = self.line_search(x, u, delta_x, delta_u, dx, x0, cost)
-                full_du_norm = (u - u_prev).norm()
+                # the reference's step-norm test runs over the WHOLE batch (qp_wrapper.py:355, 372): a rank-local norm would
+                # let the rank whose shard converges first leave the loop and pair its later all-reduces with the wrong ones
+                full_du_norm = self._global_norm(u - u_prev)
                 if best is None:
                     best = {"x": x.clone(), "u": u.clone(), "costs": cost_total.clone()}
                 else:
@@ -329,7 +340,8 @@ class MPC(Module):
                     best["x"] = torch.where(better[None, :, None], x, best["x"])
                     best["u"] = torch.where(better[None, :, None], u, best["u"])
                     best["costs"] = torch.where(better, cost_total, best["costs"])
-                if float(full_du_norm) < self.eps:
+                self.last_sqp_iters = getattr(self, "last_sqp_iters", 0) + 1
+                if full_du_norm < self.eps:
                     break
         x, u = best["x"], best["u"]
         delta_x, delta_u, _ = self.single_qp(x, u, dx, dx_jac, x0, cost)

@@ -91,6 +91,12 @@ typedef struct AlqpParams {
     int *newton_counts;   /* nullable DEVICE [al_iter]: executed Newton steps per AL iteration (-1: barrier time-out) */
     double *exit_scratch; /* DEVICE, at least 2 * B + 2 doubles, zeroed before every call (arrival counter, partial sums,
                              time-out flag: a grid barrier that waited ~1 s gives up, newton_counts then holds -1) */
+    int quad_stagger;     /* quad solve (variant 2 / auto at B >= 4096): start offset between the four wavefronts of a CU.
+                             All wavefronts run the same sweeps; started together they queue on the CU's vector-memory
+                             pipeline in lock step. 0 (default): automatic - a fifth of a sweep between neighbouring SIMDs
+                             when the grid fills the SIMDs, nx + nu >= 12 and the launch holds enough Newton steps to
+                             amortise the delay; < 0: off; > 0: that many units of ~1024 clocks. Timing only: results do
+                             not depend on it. No counterpart in the reference (a scheduling control of this library). */
 } AlqpParams;
 
 /* optional per-step trace (all nullable, for tests): S = al_iter*max_newton steps */
@@ -429,14 +435,6 @@ int alqp_ipm_backward_f64(const AlqpDims *dims, const void *Cd, const void *F, l
                           size_t ws_bytes, void *dx, void *dlam, void *dnu, int *info, int variant, void *stream);
 
 int alqp_abi_version(void);
-
-/* Quad solve (alqp_solve_lin, variant quad / auto at B >= 4096): start offset between the four wavefronts of a CU.
- * All wavefronts run the same sweeps; started together they queue on the CU's vector-memory pipeline in lock
- * step. mode -1 (default): automatic - a fifth of a sweep between neighbouring SIMDs when the grid fills the
- * SIMDs, nx + nu >= 12 and the launch holds enough Newton steps to amortise the delay; 0: off; > 0: that many units of
- * ~1024 clocks. Returns the previous mode. Results do not depend on it (it only delays wave starts).
- * No counterpart in the reference (a scheduling control of this library). */
-int alqp_set_quad_stagger(int mode);
 
 #ifdef __cplusplus
 }

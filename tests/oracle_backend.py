@@ -204,9 +204,10 @@ class OracleBackend:
 
     # ---- interior-point path (oracle/ipm_oracle.c): CPU twin of HipBackend.ipm_solve / ipm_backward ----
     def ipm_solve(self, dims, Cd, c, F, f, x0, uhi, ulo, exit_mode="reference", eps=1e-12, not_improved_lim=3,
-                  max_iter=20, ry_fn=None, process_group=None, sharded=False):
-        if sharded:
+                  max_iter=20, ry_fn=None, process_group=None, sharded=False, variant=None):
+        if sharded and exit_mode == "reference":
             raise NotImplementedError("the oracle's exit rule runs inside its C loop: sharded batches need the product backend")
+        # (exit mode "fixed" takes no batch-global decision inside the interior-point iteration: a shard is a batch)
         from oracle import ipm_py
         B, T, nx, nu = dims
         s = _sfx(c)

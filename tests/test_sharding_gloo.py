@@ -151,3 +151,62 @@ def test_sharded_stream_linearize_once_breaks_in_the_same_iteration_on_every_ran
     assert out["n_al"].tolist() == g["n_al"].tolist()
     assert out["status"].tolist() == g["status"].tolist()
     assert np.abs(out["x"] - g["x"]).max() < 2e-5 and np.abs(out["u"] - g["u"]).max() < 2e-5
+
+
+def _ip_problem(B):
+    """Nonlinear pendulum SQP problems whose first half starts AT the solution (x0 = 0, zero linear cost: the very
+    first QP returns du = 0) while the second half has real work to do."""
+    rng = np.random.default_rng(3)
+    T, nx, nu = 6, 2, 1
+    x0 = rng.standard_normal((B, nx)) * 0.5
+    c = rng.standard_normal((T, B, nx + nu)) * 0.3
+    x0[: B // 2] = 0.0
+    c[:, : B // 2] = 0.0
+    Cd = np.ones((T, B, nx + nu))
+    return T, nx, nu, x0, Cd, c
+
+
+def _ip_run(x0, Cd, c, T, nx, nu, process_group=None):
+    from deq_mpc_corl_amd import PendulumDynamics
+    from deq_mpc_corl_amd.qpth import qp_wrapper as ip
+    from tests.oracle_backend import OracleBackend
+    dt = torch.float64
+    t = lambda a: torch.as_tensor(np.ascontiguousarray(a)).to(dt)
+    dyn = PendulumDynamics()
+    B = x0.shape[0]
+    mpc = ip.MPC(nx, nu, T, u_lower=t([-2.0]), u_upper=t([2.0]), qp_iter=4, exit_unconverged=False, eps=1e-5, n_batch=B,
+                 backprop=False, verbose=0, u_init=torch.zeros(T, B, nu, dtype=dt), grad_method=ip.GradMethods.ANALYTIC,
+                 solver_type="dense", single_qp_solve=False, exit_mode="fixed", backend=OracleBackend(),
+                 process_group=process_group)
+    x, u = mpc(t(x0), ip.QuadCost(torch.diag_embed(t(Cd)), t(c)), dyn, dyn.jac)
+    return x, u, mpc.last_sqp_iters
+
+
+def _ip_worker(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    B = 8
+    T, nx, nu, x0, Cd, c = _ip_problem(B)
+    lo, hi = rank * B // world, (rank + 1) * B // world        # rank 0 owns the instances that are converged from the start
+    x, u, n_it = _ip_run(x0[lo:hi], Cd[:, lo:hi], c[:, lo:hi], T, nx, nu, process_group=dist.group.WORLD)
+    np.savez(os.path.join(out_dir, f"ip_{rank}.npz"), x=x.detach().numpy(), u=u.detach().numpy(), n_it=n_it)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_ip_sqp_loop_leaves_in_the_same_iteration_on_every_rank(tmp_path):
+    """qp_wrapper.MPC.solve_nonlin ends its SQP loop on the step norm of the WHOLE batch (reference
+    qp_wrapper.py:355, 372). Rank 0's shard has du = 0 from the first QP on; with a rank-local test it would leave the
+    loop while rank 1 is still iterating and the line search's all-reduces would pair up out of order (wrong decisions,
+    then a hang). With the norm all-reduced both ranks run the iterations the un-sharded batch runs, and the
+    concatenated result equals the un-sharded one."""
+    mp.spawn(_ip_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    B = 8
+    T, nx, nu, x0, Cd, c = _ip_problem(B)
+    x, u, n_it = _ip_run(x0, Cd, c, T, nx, nu)
+    r = [np.load(tmp_path / f"ip_{k}.npz") for k in range(2)]
+    assert int(r[0]["n_it"]) == int(r[1]["n_it"]) == n_it and n_it > 1
+    assert np.abs(np.concatenate([r[0]["x"], r[1]["x"]], axis=1) - x.detach().numpy()).max() < 1e-9
+    assert np.abs(np.concatenate([r[0]["u"], r[1]["u"]], axis=1) - u.detach().numpy()).max() < 1e-9
