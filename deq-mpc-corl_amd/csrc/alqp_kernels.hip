@@ -91,6 +91,11 @@ __device__ inline double grid_sum_ordered(double block_val, double *scratch, int
     ++phase;
     return s;
 }
+// An instance's term of the batch norm the Newton loop exits on (al_utils.py:552). One whose factorisation hit a
+// non-positive pivot counts as +inf, so that the exit does not fire: the reference's norm holds the undefined residuals
+// of such instances and ran the full 4 steps in both recorded batches (tests/test_failure_path.py).
+template <typename real>
+__device__ inline double exit_term(real r2, int info) { return info ? (double)INFINITY : (double)r2; }
 __device__ inline bool grid_barrier_timed_out(const double *scratch) {
     return __hip_atomic_load(scratch + 1 + 2 * (size_t)gridDim.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0.0;
 }
@@ -188,7 +193,7 @@ __global__ __launch_bounds__(64, OCC) void k_solve_lin(SolveArgs<real> a, TraceA
         int n_done = 0;
         if (ref_exit) {   // ||r+|| over the whole batch at the start of the Newton loop (al_utils.py:486)
             const real r0 = tm.rplus2();
-            nrm_old = sqrt(grid_sum_ordered(wave_sum_leaders((double)r0, active && li == 0), a.exit_scratch, gphase));
+            nrm_old = sqrt(grid_sum_ordered(wave_sum_leaders(exit_term(r0, tm.info), active && li == 0), a.exit_scratch, gphase));
         }
         for (int st = 0; st < a.max_newton; ++st, ++step_id) {
             real *tg = nullptr;
@@ -260,7 +265,7 @@ __global__ __launch_bounds__(64, OCC) void k_solve_lin(SolveArgs<real> a, TraceA
             phi_prev = best;  // merit <- new_merit even when rejected (al_utils.py:569)
             if (ref_exit) {   // al_utils.py:551-564, the same test alqp_exit_test takes between launches
                 const real r1 = tm.rplus2();
-                const double nw = sqrt(grid_sum_ordered(wave_sum_leaders((double)r1, active && li == 0), a.exit_scratch, gphase));
+                const double nw = sqrt(grid_sum_ordered(wave_sum_leaders(exit_term(r1, tm.info), active && li == 0), a.exit_scratch, gphase));
                 ++n_done;
                 if (nw < a.exit_tol || fabs(nrm_old - nw) / nw < a.exit_tol) break;
                 nrm_old = nw;
@@ -375,7 +380,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     qd.st_u = a.st_u;
     qd.gz = a.z + (size_t)b * T * N;
     qd.glam = a.lam + (size_t)b * M;
-    qd.rec = ws + (size_t)b * T * C::RECW;
+    qd.rec = ws + C::rec_base(b, T);
     qd.gFw = const_cast<real *>(qd.gF);
     qd.dyn_h = a.dyn_h;
     qd.rho = a.rho[b];
@@ -422,7 +427,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
         if (ref_exit) {   // ||r+|| over the whole batch at the start of the Newton loop (al_utils.py:486)
             int bad0 = 0;
             const real r0 = it == 0 ? qd.rplus2(bad0) : rn2;   // later iterations: from iter_end() of the previous one
-            nrm_old = sqrt(grid_sum_ordered(wave_sum_leaders((double)r0, active && qd.q == 0), a.exit_scratch, gphase));
+            nrm_old = sqrt(grid_sum_ordered(wave_sum_leaders(exit_term(r0, qor(qd.info)), active && qd.q == 0), a.exit_scratch, gphase));
         }
         for (int st = 0; st < a.max_newton; ++st, ++step_id) {
             real *tg = nullptr;
@@ -479,7 +484,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
                 real ph_unused = 0, r1 = 0;
                 qd.template iter_end<Dyn>(alpha_pend, pend, false, (real)a.rho_scale, false, ph_unused, r1, bad1);
                 pend = false;
-                const double nw = sqrt(grid_sum_ordered(wave_sum_leaders((double)r1, active && qd.q == 0), a.exit_scratch, gphase));
+                const double nw = sqrt(grid_sum_ordered(wave_sum_leaders(exit_term(r1, qor(qd.info)), active && qd.q == 0), a.exit_scratch, gphase));
                 ++n_done;
                 if (nw < a.exit_tol || fabs(nrm_old - nw) / nw < a.exit_tol) break;
                 nrm_old = nw;
@@ -530,7 +535,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     qd.gQd = nullptr; qd.gq = nullptr; qd.gc = nullptr; qd.gx0 = nullptr; qd.gulo = nullptr; qd.guhi = nullptr;
     qd.st_u = 0;
     qd.gz = nullptr; qd.glam = nullptr;
-    qd.rec = ws + (size_t)b * T * C::RECW;
+    qd.rec = ws + C::rec_base(b, T);
     qd.rho = a.rho[b];
     qd.info = 0;
     qd.solve_forward(a.gbar + (size_t)b * T * N);
@@ -578,7 +583,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     qd.st_u = a.st_u;
     qd.gz = const_cast<real *>(a.z) + (size_t)b * T * N;        // read-only here
     qd.glam = const_cast<real *>(a.lam) + (size_t)b * M;        // read-only here
-    qd.rec = ws + (size_t)b * T * C::RECW;
+    qd.rec = ws + C::rec_base(b, T);
     qd.gFw = const_cast<real *>(qd.gF);
     qd.dyn_h = 0;
     qd.rho = a.rho[b];
@@ -1103,7 +1108,7 @@ template int dispatch_backward_quad<double>(int, int, const BwdArgs<double> &, d
 template <typename real>
 size_t quad_ws_bytes(int nx, int nu, int B, int T) {
 #define X(NX, NU) \
-    if (nx == NX && nu == NU) return QCfg<real, NX, NU>::ws_words(B, T) * sizeof(real);
+    if (nx == NX && nu == NU) return QCfg<real, NX, NU>::ws_covers(B, T) ? QCfg<real, NX, NU>::ws_words(B, T) * sizeof(real) : 0;
     ALQP_FOR_EACH_DIMS(X)
 #undef X
     return 0;
@@ -1622,7 +1627,7 @@ __global__ void k_exit_test(const double *sumsq, double *ctl, int mode, double t
     } else if (ctl[0] == 0.0) {
         ctl[1] += 1.0;
         const double old = ctl[2];
-        if (nw < tol || fabs(old - nw) / nw < tol) ctl[0] = 1.0;
+        if (nw < tol || fabs(old - nw) / nw < tol) ctl[0] = 1.0;   // nw = inf (a tripped instance): NaN, no exit
         else ctl[2] = nw;
     }
 }

@@ -127,6 +127,18 @@ __device__ inline void gload(const real *p, real (&dst)[LEN]) {
 #ifndef ALQP_W_LDS
 #define ALQP_W_LDS 1
 #endif
+// Byte-diet upper bounds (round 3, profiles/r03/experiments/README.md): builds with one of these set drop the named
+// memory accesses WITHOUT replacing what they deliver - results are invalid, the launch time says what the real
+// change could gain at most. Never set in the product build.
+#ifndef ALQP_EXP_NOQ
+#define ALQP_EXP_NOQ 0     // diag Q neither copied into the record nor read back (uniform-Q-in-SGPRs bound)
+#endif
+#ifndef ALQP_EXP_NORS
+#define ALQP_EXP_NORS 0    // r and s neither stored nor re-read (recompute-instead-of-store bound)
+#endif
+#ifndef ALQP_EXP_NOL
+#define ALQP_EXP_NOL 0     // factor of the last ALQP_EXP_NOL stages neither stored nor re-read (LDS turn-around bound)
+#endif
 template <typename real, int SW, int N, bool IN_LDS>
 struct WPanel {
     real a[SW][N];
@@ -212,7 +224,14 @@ struct QCfg {
     __host__ __device__ static constexpr int pn(int k) { return (k & 3) * SY + (k >> 2); }
     __host__ __device__ static constexpr int px(int r) { return (r & 3) * SW + (r >> 2); }
     __host__ __device__ static constexpr int M(int T) { return T * NX + 2 * T * NU; }
+    // ONE mapping from (instance, stage) to the workspace: every kernel addresses its records through rec_base()
+    // (+ t * RECW + word), and the size the caller allocates is checked on the host against the highest word that
+    // mapping can touch (ws_covers) - so a future layout (e.g. blocks of 16 interleaved instances, where the padding
+    // quads of a batch that is not a multiple of 16 have records of their own) cannot silently outgrow ws_words().
+    __host__ __device__ static constexpr size_t rec_base(int b, int T) { return (size_t)b * T * RECW; }
     __host__ __device__ static constexpr size_t ws_words(int B, int T) { return (size_t)B * T * RECW; }
+    // padding quads alias instance B - 1 (k_*_quad: `b = active ? b_raw : B - 1`), so b never exceeds B - 1
+    __host__ static bool ws_covers(int B, int T) { return rec_base(B - 1, T) + (size_t)(T - 1) * RECW + RECW <= ws_words(B, T); }
 };
 
 template <typename real, int NX, int NU>
@@ -678,7 +697,8 @@ struct Quad {
                     bl = has ? gulo[t * st_u + jc] : real(0);
                 } else {
                     ld_own_n(rp + C::oZ, zs);
-                    ld_own_n(rp + C::oQ, Qo);
+                    if constexpr (ALQP_EXP_NOQ) { for (int m = 0; m < SY; ++m) Qo[m] = real(1); }
+                    else ld_own_n(rp + C::oQ, Qo);
                     ld_own_n(rp + C::oq, qo);
                     load_F_rows(td, W);
                     ld_own_x(rp + C::oC, cs);
@@ -719,7 +739,7 @@ struct Quad {
                     rro[s] = ok ? rr : real(0);
                     if constexpr (C::PHI0_FWD) mdist += ok ? fma_(fma_(real(0.5) * rho, rr, lm[s]), rr, real(0)) : real(0);
                 }
-                if (!EXT && dyn && active) st_own_x(rp + C::oR, rro);
+                if (!ALQP_EXP_NORS && !EXT && dyn && active) st_own_x(rp + C::oR, rro);
                 // ---- gradient and diagonal of H_tt, own elements (k = 4m + q)
                 constexpr int MU0 = NX / 4;  // first element slot that can hold a control
                 real zu = 0;                 // the control this lane owns (at most one: NU <= 4)
@@ -861,6 +881,7 @@ struct Quad {
             ALQP_STAMP(2);  // forward: panel
             // ---- stage results -> workspace (each lane its own words)
             if (active) {
+                if (!(ALQP_EXP_NOL && t >= T - ALQP_EXP_NOL))
 #pragma unroll
                 for (int s = 0; s < SH; ++s)
 #pragma unroll
@@ -925,6 +946,10 @@ struct Quad {
             const bool dyn = t < T - 1;
             real *rp = recp(t);
             real H[HT];
+            if (ALQP_EXP_NOL && t >= T - ALQP_EXP_NOL) {
+#pragma unroll
+                for (int i = 0; i < HT; ++i) H[i] = real(1);
+            } else
 #pragma unroll
             for (int s = 0; s < SH; ++s)
 #pragma unroll
@@ -945,10 +970,12 @@ struct Quad {
             real lu = 0, ll = 0, bu = 0, bl = 0;
             if constexpr (LS) {
                 ld_own_n(rp + C::oZ, zz);
-                ld_own_n(rp + C::oQ, QQ);
+                if constexpr (ALQP_EXP_NOQ) { for (int m = 0; m < SY; ++m) QQ[m] = real(1); }
+                else ld_own_n(rp + C::oQ, QQ);
                 ld_own_n(rp + C::oq, qq);
                 ld_own_us(rp, lu, ll, bu, bl);
-                ld_own_x(rp + C::oR, rv);
+                if constexpr (ALQP_EXP_NORS) { for (int s = 0; s < SW; ++s) rv[s] = real(0); }
+                else ld_own_x(rp + C::oR, rv);
                 ld_own_x(rp + C::oLE, lv);
             }
             ALQP_STAMP(4);  // backward: exposed load latency
@@ -1004,7 +1031,7 @@ struct Quad {
                     for (int k = 0; k < N; ++k) p = fma_(W[s][k], Y[k], p);
                     sv[s] = (4 * s + 3 < NX || r < NX) ? dxs[s] - p : real(0);
                 }
-                if (active && !d_ext) st_own_x(rp + C::oS, sv);
+                if (!ALQP_EXP_NORS && active && !d_ext) st_own_x(rp + C::oS, sv);
             }
             if constexpr (LS) {
                 real zu = 0, du = 0;   // the control this lane owns (at most one: NU <= 4)
@@ -1171,11 +1198,12 @@ struct Quad {
             real lu, ll, bu, bl;
             ld_own_n(rp + C::oZ, zz);
             ld_own_n(rp + C::oY, dd);
-            ld_own_n(rp + C::oQ, QQ);
+            if constexpr (ALQP_EXP_NOQ) { for (int m = 0; m < SY; ++m) QQ[m] = real(1); }
+            else ld_own_n(rp + C::oQ, QQ);
             ld_own_n(rp + C::oq, qq);
             ld_own_us(rp, lu, ll, bu, bl);
-            ld_own_x(rp + C::oR, rv);
-            ld_own_x(rp + C::oS, sv);
+            if constexpr (ALQP_EXP_NORS) { for (int s = 0; s < SW; ++s) rv[s] = sv[s] = real(0); }
+            else { ld_own_x(rp + C::oR, rv); ld_own_x(rp + C::oS, sv); }
             ld_own_x(rp + C::oLE, lv);
             real zu = 0, du = 0;   // the control this lane owns (at most one: NU <= 4)
 #pragma unroll
@@ -1248,11 +1276,12 @@ struct Quad {
             real lu, ll, bu, bl;
             ld_own_n(rp + C::oZ, zz);
             ld_own_n(rp + C::oY, dd);
-            ld_own_n(rp + C::oQ, QQ);
+            if constexpr (ALQP_EXP_NOQ) { for (int m = 0; m < SY; ++m) QQ[m] = real(1); }
+            else ld_own_n(rp + C::oQ, QQ);
             ld_own_n(rp + C::oq, qq);
             ld_own_us(rp, lu, ll, bu, bl);
-            ld_own_x(rp + C::oR, rv);
-            ld_own_x(rp + C::oS, sv);
+            if constexpr (ALQP_EXP_NORS) { for (int s = 0; s < SW; ++s) rv[s] = sv[s] = real(0); }
+            else { ld_own_x(rp + C::oR, rv); ld_own_x(rp + C::oS, sv); }
             ld_own_x(rp + C::oLE, lv);
             real rtrue[SW];
 #pragma unroll

@@ -332,22 +332,34 @@ class MPC(Module):
             return torch.full((B,), float(r), dtype=dtype, device=device)
         return r.to(device=device, dtype=dtype).reshape(B).contiguous().clone()
 
-    def _global_sumsq(self, rn2):
+    @staticmethod
+    def _exit_terms(rn2, info):
+        """Per-instance terms of the batch norm the Newton loop exits on. An instance whose factorisation hit a
+        non-positive pivot (sticky info != 0) counts as +inf: the exit then never fires in this call. The reference's
+        norm (torch.norm(dyn_res), al_utils.py:552) holds the UNDEFINED residuals of such instances (half-finished
+        Cholesky factor, :510-515) and kept both recorded batches at the full 4 Newton steps
+        (tests/golden/fail_*.npz: newton_per_al = [4]); without its garbage the healthy instances alone would stop
+        after 3 and end 0.03 / 0.06 (fp64 / fp32) away from the reference's controls."""
+        if info is None:
+            return rn2
+        return torch.where(info != 0, torch.full_like(rn2, float("inf")), rn2)
+
+    def _global_sumsq(self, rn2, info=None):
         """sum_b sum_rows r+^2 as a 1-element float64 device tensor (all-reduced over the ranks
         of a sharded batch); nothing is synchronised with the host."""
-        s = rn2.sum(dtype=torch.float64).reshape(1)
+        s = self._exit_terms(rn2, info).sum(dtype=torch.float64).reshape(1)
         if self.process_group is not None or (
                 torch.distributed.is_available() and torch.distributed.is_initialized()
                 and getattr(self, "sync_global_exit", False)):
             torch.distributed.all_reduce(s, group=self.process_group)
         return s
 
-    def _global_norm(self, rn2):
+    def _global_norm(self, rn2, info=None):
         """sqrt(sum_b sum_rows r+^2): the batch-global quantity the reference exits on
         (torch.norm(dyn_res).item(), al_utils.py:486,552). With a sharded batch the
         partial sums are all-reduced (8 bytes over RCCL) so that every rank takes the
         same decision the un-sharded reference would."""
-        s = rn2.sum(dtype=torch.float64)
+        s = self._exit_terms(rn2, info).sum(dtype=torch.float64)
         if self.process_group is not None or (
                 torch.distributed.is_available() and torch.distributed.is_initialized()
                 and getattr(self, "sync_global_exit", False)):
@@ -437,14 +449,14 @@ class MPC(Module):
         # MAX_NEWTON launches are enqueued, each one a no-op once ctl[0] is set, and the number of
         # executed steps (ctl[1]) is read back once per solve. No host round trip per Newton step.
         ctl = torch.zeros(3, dtype=torch.float64, device=st.z.device)
-        be.exit_test(self._global_sumsq(ws["rn2"]), ctl, 0)
+        be.exit_test(self._global_sumsq(ws["rn2"], ws["info"]), ctl, 0)
         for _ in range(MAX_NEWTON):
             # same workspace as the launch before, nothing touched in between: no copy-in pass
             be.solve_lin(dims, Qd, q, F, c, st.x0, lo, hi, sb, stt, st.z, st.lam, st.rho, ws["phi"],
                          factor=ws.get("factor"), al_iter=1, max_newton=1,
                          flags=fl_save | (0 if fl_save else pflag()), skip=ctl, **common)
             after()
-            be.exit_test(self._global_sumsq(ws["rn2"]), ctl, 1)
+            be.exit_test(self._global_sumsq(ws["rn2"], ws["info"]), ctl, 1)
         return ctl
 
     def _newton_al_fused_nl(self, st, Qd, q, bnd, ws):
@@ -458,10 +470,10 @@ class MPC(Module):
         args = (dims, st.dx.fused_id, st.dx.dt, Qd, q, st.x0, lo, hi, sb, stt, st.z, st.lam, st.rho, ws["phi"])
         be.solve_nonlin(*args, al_iter=1, max_newton=0, flags=_abi.ALQP_INIT_MERIT, **common)
         ctl = torch.zeros(3, dtype=torch.float64, device=st.z.device)
-        be.exit_test(self._global_sumsq(ws["rn2"]), ctl, 0)
+        be.exit_test(self._global_sumsq(ws["rn2"], ws["info"]), ctl, 0)
         for _ in range(MAX_NEWTON):
             be.solve_nonlin(*args, al_iter=1, max_newton=1, flags=0, skip=ctl, **common)
-            be.exit_test(self._global_sumsq(ws["rn2"]), ctl, 1)
+            be.exit_test(self._global_sumsq(ws["rn2"], ws["info"]), ctl, 1)
         return ctl
 
     def _linearize(self, st, z):
@@ -498,7 +510,7 @@ class MPC(Module):
         okw = self._obs_kwargs(dt, z.device)   # {} or {"obs": (centres, radius)} (Obstacle_MPC)
         xn = dyn(z)
         be.merit(dims, 1, z, xn, st.x0, st.lam, st.rho, Qd, q, lo, hi, sb, stt, ws["phi"], ws["rn2"], **okw)
-        old = self._global_norm(ws["rn2"]) if self.exit_mode == "reference" else None
+        old = self._global_norm(ws["rn2"], ws["info"]) if self.exit_mode == "reference" else None
         alphas = (2.0 ** -torch.arange(N_LS, device=z.device, dtype=dt)).view(N_LS, 1, 1, 1)
         steps = 0
         while steps < MAX_NEWTON:
@@ -523,8 +535,8 @@ class MPC(Module):
             be.merit_pick(dims, N_LS, ws["d"], xnc, st.x0, st.lam, st.rho, Qd, q, lo, hi, sb, stt, z, ws["phi"],
                           rnorm2=ws["rn2"], k_out=ws["k"], accept_out=ws["acc"], **okw)
             if self.exit_mode == "reference":
-                new = self._global_norm(ws["rn2"])
-                if new < 1e-3 or abs(old - new) / new < 1e-3:
+                new = self._global_norm(ws["rn2"], ws["info"])
+                if new < 1e-3 or (math.isfinite(new) and abs(old - new) / new < 1e-3):   # inf: a tripped instance, no exit
                     break
                 old = new
         return steps

@@ -23,18 +23,19 @@ TD = {"f64": torch.float64, "f32": torch.float32}
 FAIL = ["fail_cart_f64", "fail_quad13_f32"]
 
 
-def _run(name, backend, dev, **kw):
+def _run(name, backend, dev, exit_mode="fixed", **kw):
     from deq_mpc_corl_amd import MPC, AffineDynamics, QuadCost
     g = gu.load(name)
     dt = TD[g["dtype"]]
     B, T, nx, nu = g["B"], g["T"], g["nx"], g["nu"]
     tt = lambda a: torch.as_tensor(np.ascontiguousarray(a)).to(dt).to(dev)
     dyn = AffineDynamics(tt(g["F"]), tt(g["c"]))
-    # exit_mode "fixed": the reference ran all 4 Newton steps in both fixtures; its batch-global exit norm
-    # (al_utils.py:552) is dominated by the tripped instances' undefined residuals, so the reference-exit
-    # rule would tie the healthy instances' step count to them (3 instead of 4 steps with the |p| policy)
+    # The reference ran all 4 Newton steps in both fixtures: its batch-global exit norm (al_utils.py:552) holds the
+    # tripped instances' undefined residuals. exit_mode "fixed" runs 4 steps by construction; the default "reference"
+    # mode (round 3) counts a tripped instance as +inf in that norm, so the exit cannot fire either - without that the
+    # healthy instances alone stop after 3 steps and end 0.03 (fp64) / 0.06 (fp32) away from the reference's controls.
     mpc = MPC(nx, nu, T, u_lower=tt(g["u_lo"]), u_upper=tt(g["u_hi"]), n_batch=B, dtype=dt, backend=backend,
-              exit_mode="fixed", **kw)
+              exit_mode=exit_mode, **kw)
     mpc.reinitialize(tt(g["x0"]), None)
     mpc.rho_prev = tt(g["rho_init"]).reshape(B, 1)
     mpc.al_iter = g["al_iter"]
@@ -62,19 +63,23 @@ def _check(g, mpc, x, u):
 
 
 @pytest.mark.parametrize("name", FAIL)
-def test_failure_path_cpu(name):
+@pytest.mark.parametrize("exit_mode", ["fixed", "reference"])
+def test_failure_path_cpu(name, exit_mode):
     from tests.oracle_backend import OracleBackend
-    _check(*_run(name, OracleBackend(), "cpu"))
+    _check(*_run(name, OracleBackend(), "cpu", exit_mode=exit_mode))
 
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("name", FAIL)
 @pytest.mark.parametrize("variant", ["team", "quad"])
-def test_failure_path_hip(name, variant):
+@pytest.mark.parametrize("exit_mode", ["fixed", "reference"])
+def test_failure_path_hip(name, variant, exit_mode):
+    """"reference" = the drop-in class's default: on these batch sizes the team variant takes the exit test INSIDE one
+    cooperative launch (exit_term in the kernels), the quad variant between launches (MPC._exit_terms)."""
     from deq_mpc_corl_amd.backend import HipBackend
     be = HipBackend()
     be.default_variant = variant
-    _check(*_run(name, be, "cuda:0"))
+    _check(*_run(name, be, "cuda:0", exit_mode=exit_mode))
 
 
 def test_check_numerics_warns_and_raises():

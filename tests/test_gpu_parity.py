@@ -81,10 +81,17 @@ def near_tie_instances(o, dtype):
     return tie
 
 
-def check_excluded(dtype, excluded, zg, lamg, rho, o, prob, max_frac=0.10, label=""):
+# Near-tie instances are a property of the ORACLE's trace on the seeded problem (near_tie_instances), so their number is
+# known without a GPU: counted on the CPU for every budgeted test (round 3); each budget below is that count + 1.
+NEAR_TIES_DIMS_F32 = {(2, 1): 0, (4, 1): 1, (4, 2): 0, (6, 1): 5, (6, 2): 5, (8, 2): 1, (10, 3): 2, (12, 4): 5, (13, 4): 2, (14, 4): 3}
+NEAR_TIES_T50 = {"f32": 1, "f64": 0}
+NEAR_TIES_FULL = {"pend": 3, "(8,2": 1, "(13,": 4}
+
+
+def check_excluded(dtype, excluded, zg, lamg, rho, o, prob, max_count=1, label=""):
     """fp32 accounting (an instance whose 20-point line search met a near-tie may take another step than
     the oracle and is left out of the element-wise comparison - but not out of every check):
-      * the excluded fraction is printed and bounded (<= max_frac, at least one instance allowed);
+      * the excluded number is printed and bounded by max_count = the number counted on the CPU for this test + 1;
       * every excluded instance's GPU iterate is finite;
       * its merit, re-evaluated BY THE ORACLE at the GPU's (z, lam, rho), is no worse than the oracle's own
         final merit + 1e-3 (|phi| + 1): a different tie-break must not be a worse point.
@@ -92,7 +99,7 @@ def check_excluded(dtype, excluded, zg, lamg, rho, o, prob, max_frac=0.10, label
     B = len(excluded)
     n_ex = int(excluded.sum())
     print(f"[fp32 accounting] {label}: {n_ex}/{B} instances excluded as line-search near-ties ({100.0 * n_ex / B:.1f} %)")
-    assert n_ex <= max(1, int(max_frac * B)), (label, n_ex, B)
+    assert n_ex <= max_count, (label, n_ex, max_count, B)
     if n_ex == 0:
         return
     assert np.isfinite(zg[excluded]).all() and np.isfinite(lamg[excluded]).all(), label
@@ -320,8 +327,8 @@ def test_every_compiled_dims_vs_oracle(nx, nu, dtype, variant):
     assert int(info.abs().sum()) == 0
     ok = ~near_tie_instances(o, dtype)
     prob = dict(Qd=c(p.Qd), q=c(p.q), F=c(p.F), c=c(p.c), x0=c(p.x0), u_lo=c(p.u_lo), u_hi=c(p.u_hi))
-    # measured at this seed (B = 19, T = 7): at most 5 of 19 instances ((6,1), (6,2), (12,4)); 0-3 elsewhere
-    check_excluded(dtype, ~ok, c(z), c(lam), c(rho), o, prob, max_frac=0.27, label=f"({nx},{nu})/{dtype}/{variant}")
+    budget = (NEAR_TIES_DIMS_F32[(nx, nu)] if dtype == "f32" else 0) + 1
+    check_excluded(dtype, ~ok, c(z), c(lam), c(rho), o, prob, max_count=budget, label=f"({nx},{nu})/{dtype}/{variant}")
     assert np.abs(c(z) - o["z"])[ok].max() < tol
     assert np.abs(c(lam) - o["lam"])[ok].max() < tol * 20
 
@@ -353,7 +360,7 @@ def test_long_horizon_T50(variant):
         ok = ~near_tie_instances(o, dtype)
         assert int(info.abs().sum()) == 0
         prob = dict(Qd=c(p.Qd), q=c(p.q), F=c(p.F), c=c(p.c), x0=c(p.x0), u_lo=c(p.u_lo), u_hi=c(p.u_hi))
-        check_excluded(dtype, ~ok, c(z), c(lam), c(rho), o, prob, max_frac=0.16, label=f"T50/{dtype}/{variant}")
+        check_excluded(dtype, ~ok, c(z), c(lam), c(rho), o, prob, max_count=NEAR_TIES_T50[dtype] + 1, label=f"T50/{dtype}/{variant}")
         assert np.abs(c(z) - o["z"])[ok].max() < (1e-9 if dtype == "f64" else 3e-3)
 
 
@@ -475,5 +482,5 @@ def test_baseline_configs_full_size_properties(cfg):
                       p.u_hi.cpu().numpy(), c(p.z0), al_iter=2, exit_mode="fixed", trace_steps=8)
     ok = ~near_tie_instances(o, "f32")
     prob = dict(Qd=c(p.Qd), q=c(p.q), F=c(p.F), c=c(p.c), x0=c(p.x0), u_lo=p.u_lo.cpu().numpy(), u_hi=p.u_hi.cpu().numpy())
-    check_excluded("f32", ~ok, c(z), c(lam), np.full(len(idx), 100.0, np.float32), o, prob, max_frac=0.27, label=cfg)
+    check_excluded("f32", ~ok, c(z), c(lam), np.full(len(idx), 100.0, np.float32), o, prob, max_count=NEAR_TIES_FULL[cfg[:4]] + 1, label=cfg)
     assert np.abs(c(z) - o["z"])[ok].max() < 5e-3
