@@ -211,6 +211,10 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "hbm_traffic_frac": (traffic / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
                          "valu_frac": flops / (kernel_ms * 1e-3) / 1e12 / VALU_PEAK_TFLOPS[args.dtype],
+                         # achieved solves/s over what the vector peak allows for this arithmetic (65 M solves/s in fp32 at
+                         # (20,13,4)): the ceiling of the fused unit, which the algorithmic HBM roof (300 M solves/s) is not
+                         "valu_capped_frac": flops / (kernel_ms * 1e-3) / 1e12 / VALU_PEAK_TFLOPS[args.dtype],
+                         "valu_cap_solves_per_s": B * VALU_PEAK_TFLOPS[args.dtype] * 1e12 / flops,
                          "valu_peak_tflops": VALU_PEAK_TFLOPS[args.dtype], "flops_per_launch_est": flops,
                          "kernel": KERNEL_OF[variant], "kernel_ms": kernel_ms,
                          "algorithmic_bytes_per_launch": alg_bytes,

@@ -96,11 +96,11 @@ def _replay_ip(name, backend, dev, exit_mode="reference", variant=None):
     x, u = mpc(tt(g["x0"]), ip.QuadCost(torch.diag_embed(Cd), c), dx, dx_jac)
     assert x.shape == (T, B, nx) and u.shape == (T, B, nu)
     f64 = g["dtype"] == "f64"
-    # fp32: ~20 KKT solves at a conditioning of ~1e7 (D~ = z/s spans 1e-7..1e7 near convergence) leave the size-generic
-    # kernel's controls at a noise floor of a few 1e-3 against the reference's fp32 run; the register-resident kernel
-    # (root-free L D L' with the refinement step) lands within 2e-5 of it on all three fp32 fixtures (counted in the CPU
-    # wave emulator, tests/test_ipm_g4_emu.py), so it is held to 5e-4
-    tol = 1e-7 if f64 else (5e-4 if variant == "resident" else 1e-2)
+    # fp32: ~20 KKT solves at a conditioning of ~1e7 (D~ = z/s spans 1e-7..1e7 near convergence) leave the returned
+    # controls at a noise floor of a few 1e-3 on both sides (the reference's fp32 run and ours): measured on the MI355X
+    # 4.5e-3 on ip_quad13_f32 with the register-resident kernel (hardware reciprocals), 1e-6 on the two small fixtures;
+    # the same kernel source with exact divisions (CPU wave emulator, tests/test_ipm_g4_emu.py) is within 2e-5
+    tol = 1e-7 if f64 else 1e-2
     if f64 and exit_mode == "reference":
         assert mpc.last_ipm["iters"] == int(g["ipm_iters"][-1])
     ex = np.abs(x.detach().cpu().numpy() - g["x"]).max()
