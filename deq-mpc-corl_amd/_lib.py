@@ -41,6 +41,13 @@ class AlqpIpmParams(C.Structure):
                 ("variant", C.c_int)]
 
 
+class AlqpRigidParams(C.Structure):
+    _fields_ = [("mass", C.c_double), ("J", C.c_double * 9), ("Jinv", C.c_double * 9), ("g", C.c_double * 3),
+                ("motor_dist", C.c_double), ("kf", C.c_double), ("bf", C.c_double), ("km", C.c_double),
+                ("act_scale", C.c_double), ("u_hover", C.c_double), ("pend_L", C.c_double), ("ss", C.c_double * 12),
+                ("bf_force", C.c_double)]
+
+
 IPM_VARIANTS = {"auto": 0, "generic_lds": 1, "generic_ws": 2, "resident": 3}   # ALQP_IPM_VARIANT_*
 
 
@@ -65,6 +72,8 @@ _SIGS = {
     "alqp_dyn_cartpole1l": (C.c_int, [C.c_long, _P, _P, C.c_double, _P, _P, _P, _P]),
     "alqp_dyn_cartpole1l_v2": (C.c_int, [C.c_long, _P, _P, C.c_double, _P, _P, _P, _P]),
     "alqp_dyn_cartpole2l": (C.c_int, [C.c_long, _P, _P, C.c_double, _P, _P, _P, _P]),
+    "alqp_dyn_rexquadrotor": (C.c_int, [C.c_long, C.POINTER(AlqpRigidParams), _P, _P, C.c_double, _P, _P, _P]),
+    "alqp_dyn_flyingcartpole": (C.c_int, [C.c_long, C.POINTER(AlqpRigidParams), _P, _P, C.c_double, _P, _P, _P]),
     "alqp_solve_lin": (C.c_int, [C.POINTER(AlqpDims), C.POINTER(AlqpParams), _P, _P, _P, _P, _P, _P, _P,
                                  C.c_long, C.c_long, _P, _P, _P, _P, _P, _P, _P, _P,
                                  C.POINTER(AlqpTrace), _P, C.c_size_t, _P]),

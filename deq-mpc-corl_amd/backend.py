@@ -260,6 +260,21 @@ class HipBackend:
         _lib.check(rc, "alqp_dyn_cartpole2l")
         return xn, J
 
+    def dyn_rigid(self, model, params, x, u, h, want_jac=True):
+        """Quadrotor / flying-cartpole provider (alqp_dyn_rexquadrotor / alqp_dyn_flyingcartpole): model "rex" (x [K,12])
+        or "flycart" (x [K,14]), u [K,4], params an _lib.AlqpRigidParams -> xnext [K,nx], F = [A | B] [K,nx,nx+4] or None."""
+        K, nx = x.shape
+        dt = x.dtype
+        xn = torch.empty(K, nx, dtype=dt, device=x.device)
+        F = torch.empty(K, nx, nx + 4, dtype=dt, device=x.device) if want_jac else None
+        name = {"rex": "alqp_dyn_rexquadrotor_", "flycart": "alqp_dyn_flyingcartpole_"}[model]
+        if nx != {"rex": 12, "flycart": 14}[model] or u.shape != (K, 4):
+            raise ValueError(f"mi_alqp: {model} dynamics take x [K,{ {'rex': 12, 'flycart': 14}[model] }] and u [K,4]")
+        rc = getattr(self.lib, name + _dt(x))(K, C.byref(params), _ptr(x, "x", dt), _ptr(u, "u", dt), float(h),
+                                             _ptr(xn, "xnext", dt), _ptr(F, "F", dt, True), _stream())
+        _lib.check(rc, name)
+        return xn, F
+
     def exit_test(self, sumsq, ctl, mode, tol=1e-3):
         """Device-side batch-global exit test (alqp_exit_test): sumsq 0-d/1-elem float64 tensor,
         ctl float64[3] = {done, steps, old_norm}; nothing is synchronised."""

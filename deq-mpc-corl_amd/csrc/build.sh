@@ -21,6 +21,8 @@ hipcc $FLAGS -DALQP_G4_F64 -c alqp_ipm_g4.hip -o build/alqp_ipm_g4_f64.o "$@" &
 pids+=($!)
 hipcc $FLAGS -DALQP_G4_F32 -c alqp_ipm_g4.hip -o build/alqp_ipm_g4_f32.o "$@" &
 pids+=($!)
+hipcc $FLAGS -c alqp_dyn_rigid.hip -o build/alqp_dyn_rigid.o "$@" &   # quadrotor / flying-cartpole dynamics providers
+pids+=($!)
 for p in "${pids[@]}"; do wait "$p"; done
 hipcc --offload-arch=gfx950 -shared -fPIC build/alqp_part1.o build/alqp_part2.o build/alqp_part3.o build/alqp_ipm.o \
-  build/alqp_ipm_g4_f64.o build/alqp_ipm_g4_f32.o -o libmi_alqp.so
+  build/alqp_ipm_g4_f64.o build/alqp_ipm_g4_f32.o build/alqp_dyn_rigid.o -o libmi_alqp.so

@@ -12,4 +12,5 @@ __path__.insert(0, _os.path.join(_os.path.dirname(_os.path.dirname(_os.path.absp
 from .qpth.al_utils import LinDx, QuadCost  # noqa: E402,F401
 from .qpth.AL_mpc import MPC  # noqa: E402,F401
 from .problems import AffineDynamics, PendulumDynamics, synthetic_problem  # noqa: E402,F401
-from .dynamics import Cartpole1lDynamics, Cartpole1lV2Dynamics, Cartpole2lDynamics, Pendulum1lDynamics  # noqa: E402,F401
+from .dynamics import (Cartpole1lDynamics, Cartpole1lV2Dynamics, Cartpole2lDynamics, FlyingCartpoleDynamics,  # noqa: E402,F401
+                       Pendulum1lDynamics, RexQuadrotorDynamics)

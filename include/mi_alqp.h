@@ -434,6 +434,33 @@ int alqp_ipm_backward_f64(const AlqpDims *dims, const void *Cd, const void *F, l
                           long sF_b, const void *lams, const void *slacks, const void *gbar, void *workspace,
                           size_t ws_bytes, void *dx, void *dlam, void *dnu, int *info, int variant, void *stream);
 
+/*
+ * ---- Dynamics + Jacobian providers of the reference's torch-coded robots -----------
+ * RexQuadrotor (deqmpc/rex_quadrotor.py:98-144; x = (r, MRP, body velocity, body rate) [12], u [4]) and FlyingCartpole
+ * (deqmpc/flying_cartpole2d.py:81-148; x = (r, MRP, theta, v, w, theta') [14], u [4]): one RK4 step of length h,
+ * x+ [K][nx] and F = [A | B] = d x+ / d (x, u) [K][nx][nx+nu] (either output may be NULL). They replace the
+ * reference's `dynamics` TorchScript module and its replicate-nx-times autograd Jacobian (rex_quadrotor.py:136-144).
+ * PARITY UNPINNED: the reference files import `rexquad_utils`, which is not in the tree; mrp2quat, quatrot and
+ * w2pdotkinematics_mrp are restated from their standard definitions (csrc/alqp_dyn_rigid.hip, oracle/rigid_py.py).
+ * The struct carries the constructor values of the reference classes (the Python side fills it, rounding through
+ * float32 where the reference builds float32 tensors).
+ */
+typedef struct AlqpRigidParams {
+    double mass;        /* quadrotor: mass; flying cartpole: mass_q + mass_p */
+    double J[9], Jinv[9];
+    double g[3];
+    double motor_dist, kf, bf, km;
+    double act_scale;   /* 100 (quadrotor) / 10 (flying cartpole) */
+    double u_hover;     /* flying cartpole: u <- act_scale (u + u_hover); 0 for the quadrotor */
+    double pend_L;      /* flying cartpole: pendulum length */
+    double ss[12];      /* motor arm directions [4][3], normalised */
+    double bf_force;    /* quadrotor: Bf_z = 4 bf (rex_quadrotor.py:31-32) */
+} AlqpRigidParams;
+int alqp_dyn_rexquadrotor_f32(long K, const AlqpRigidParams *p, const void *x, const void *u, double h, void *xnext, void *F, void *stream);
+int alqp_dyn_rexquadrotor_f64(long K, const AlqpRigidParams *p, const void *x, const void *u, double h, void *xnext, void *F, void *stream);
+int alqp_dyn_flyingcartpole_f32(long K, const AlqpRigidParams *p, const void *x, const void *u, double h, void *xnext, void *F, void *stream);
+int alqp_dyn_flyingcartpole_f64(long K, const AlqpRigidParams *p, const void *x, const void *u, double h, void *xnext, void *F, void *stream);
+
 int alqp_abi_version(void);
 
 #ifdef __cplusplus

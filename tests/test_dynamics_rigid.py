@@ -1,0 +1,145 @@
+"""Dynamics + Jacobian providers of the reference's torch-coded robots: RexQuadrotor
+(deqmpc/rex_quadrotor.py:98-144) and FlyingCartpole (deqmpc/flying_cartpole2d.py:81-148).
+
+PARITY UNPINNED - stated here as in DESIGN.md: the reference files import `rexquad_utils`, which is not in the tree, so
+they cannot be imported or run and no output of them exists; `mrp2quat`, `quatrot`, `w2pdotkinematics_mrp` are restated
+from their standard definitions. What these tests DO pin:
+  * the torch restatement (oracle/rigid_py.py, the reference's equations line by line around those three helpers):
+    autograd Jacobian == central differences, hover is an equilibrium, the rotation preserves norms, the MRP
+    kinematics reduce to m' = w / 4 at m = 0 (CPU);
+  * the HIP kernels == that restatement in value, and their Jacobian == its autograd Jacobian and central differences
+    of the KERNEL's own values (-m gpu), ragged batch sizes, both dtypes; an MPC driven by the provider.
+"""
+import numpy as np
+import pytest
+import torch
+
+MODELS = ["rex", "flycart"]
+
+
+def _params(model):
+    from oracle import rigid_py as rp
+    return rp.rex_params() if model == "rex" else rp.flycart_params()
+
+
+def _points(model, K, seed=0, scale=0.3):
+    g = torch.Generator().manual_seed(seed)
+    nx = 12 if model == "rex" else 14
+    x = scale * torch.randn(K, nx, generator=g, dtype=torch.float64)
+    u = 0.2 * torch.randn(K, 4, generator=g, dtype=torch.float64)
+    if model == "rex":
+        P = _params(model)
+        u = u + (-P["mass"] * P["g"][2] - P["bf"] * 4) / 100 / P["kf"] / 4     # around hover (rex_quadrotor.py:44)
+    return x, u
+
+
+@pytest.mark.parametrize("model", MODELS)
+def test_restatement_autograd_equals_central_differences(model):
+    from oracle import rigid_py as rp
+    P = _params(model)
+    x, u = _points(model, 6)
+    nx = x.shape[1]
+    J = rp.jacobian(P, x, u)
+    eps = 1e-6
+    z = torch.cat([x, u], 1)
+    for j in range(nx + 4):
+        zp, zm = z.clone(), z.clone()
+        zp[:, j] += eps
+        zm[:, j] -= eps
+        fd = (rp.step(P, zp[:, :nx], zp[:, nx:]) - rp.step(P, zm[:, :nx], zm[:, nx:])) / (2 * eps)
+        assert (J[:, :, j] - fd).abs().max() < 2e-7 * max(1.0, float(J.abs().max()))
+
+
+@pytest.mark.parametrize("model", MODELS)
+def test_restatement_physical_invariants(model):
+    from oracle import rigid_py as rp
+    P = _params(model)
+    nx = 12 if model == "rex" else 14
+    # hover: at rest, level, with the hover command nothing moves (constants are float32-rounded: 1e-7)
+    x0 = torch.zeros(1, nx, dtype=torch.float64)
+    uh = torch.zeros(1, 4, dtype=torch.float64)
+    if model == "rex":
+        uh += (-P["mass"] * P["g"][2] - P["bf"] * 4) / 100 / P["kf"] / 4
+    assert (rp.step(P, x0, uh) - x0).abs().max() < 1e-6
+    # quatrot(mrp2quat(m), v) is a rotation: norms and the identity at m = 0
+    m = 0.5 * torch.randn(16, 3, dtype=torch.float64)
+    v = torch.randn(16, 3, dtype=torch.float64)
+    r = rp.quatrot(rp.mrp2quat(m), v)
+    assert (r.norm(dim=-1) - v.norm(dim=-1)).abs().max() < 1e-12
+    assert (rp.quatrot(rp.mrp2quat(torch.zeros(16, 3, dtype=torch.float64)), v) - v).abs().max() == 0
+    back = rp.quatrot(rp.mrp2quat(-m), r)                      # the inverse rotation (what `forces` uses for gravity)
+    assert (back - v).abs().max() < 1e-12
+    # MRP kinematics at small angles: m' = w / 4
+    w = torch.randn(16, 3, dtype=torch.float64)
+    assert (rp.w2pdotkinematics_mrp(torch.zeros(16, 3, dtype=torch.float64), w) - 0.25 * w).abs().max() == 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("model", MODELS)
+@pytest.mark.parametrize("dtype,tol", [(torch.float64, 1e-11), (torch.float32, 2e-4)])
+@pytest.mark.parametrize("K", [1, 37, 1000])
+def test_rigid_provider_kernel_vs_restatement(model, dtype, tol, K):
+    from deq_mpc_corl_amd import FlyingCartpoleDynamics, RexQuadrotorDynamics
+    from oracle import rigid_py as rp
+    P = _params(model)
+    dyn = RexQuadrotorDynamics() if model == "rex" else FlyingCartpoleDynamics()
+    x, u = _points(model, K, seed=K)
+    nx = x.shape[1]
+    xd, ud = x.to("cuda:0", dtype), u.to("cuda:0", dtype)
+    xn = dyn(xd, ud)
+    xn2, (A, B) = dyn.jac(xd, ud)
+    assert torch.equal(xn, xn2)
+    ref = rp.step(P, x, u)
+    scale = max(1.0, float(ref.abs().max()))
+    assert (xn.cpu().double() - ref).abs().max() < tol * scale
+    Kj = min(K, 8)
+    J = rp.jacobian(P, x[:Kj], u[:Kj])
+    Jg = torch.cat([A, B], -1)[:Kj].cpu().double()
+    assert (Jg - J).abs().max() < tol * 10 * max(1.0, float(J.abs().max()))
+    if dtype == torch.float64:      # the kernel's Jacobian against central differences of the kernel's own values
+        eps = 1e-6
+        for j in (0, 4, 7, nx - 1, nx, nx + 3):
+            zp, zm = torch.cat([x, u], 1)[:Kj].clone(), torch.cat([x, u], 1)[:Kj].clone()
+            zp[:, j] += eps
+            zm[:, j] -= eps
+            f = lambda z: dyn(z[:, :nx].to("cuda:0"), z[:, nx:].to("cuda:0")).cpu()
+            fd = (f(zp) - f(zm)) / (2 * eps)
+            assert (Jg[:, :, j] - fd).abs().max() < 5e-7 * max(1.0, float(J.abs().max()))
+
+
+@pytest.mark.gpu
+def test_mpc_driven_by_the_quadrotor_provider():
+    """The drop-in MPC in nonlinear-caller mode with the kernel provider as dx / dx_jac against the same MPC with the
+    torch restatement (autograd Jacobians) as dynamics: same Newton-step counts, same trajectory."""
+    from deq_mpc_corl_amd import MPC, QuadCost, RexQuadrotorDynamics
+    from oracle import rigid_py as rp
+    P = rp.rex_params()
+    dt = torch.float64
+    dev = "cuda:0"
+    B, T, nx, nu = 6, 8, 12, 4
+    dyn = RexQuadrotorDynamics()
+    g = torch.Generator().manual_seed(1)
+    x0 = (0.1 * torch.randn(B, nx, generator=g, dtype=dt)).to(dev)
+    Qd = torch.tensor([10.0] * 6 + [1.0] * 6 + [1e-8] * 4, dtype=dt, device=dev).expand(B, T, nx + nu).contiguous()
+    q = torch.zeros(B, T, nx + nu, dtype=dt, device=dev)
+    uh = dyn.u_hover
+
+    class Ref:   # the restatement on the CPU, moved per call (test only)
+        def __call__(self, x, u):
+            return rp.step(P, x.cpu(), u.cpu()).to(dev)
+
+        def jac(self, x, u):
+            J = rp.jacobian(P, x.detach().cpu(), u.detach().cpu()).to(dev)
+            return self(x.detach(), u.detach()), (J[..., :nx], J[..., nx:])
+
+    outs = []
+    for d in (dyn, Ref()):
+        mpc = MPC(nx, nu, T, u_lower=torch.full((nu,), uh - 0.5, dtype=dt, device=dev),
+                  u_upper=torch.full((nu,), uh + 0.5, dtype=dt, device=dev), n_batch=B, dtype=dt)
+        mpc.reinitialize(x0, None)
+        mpc.al_iter = 2
+        x, u, _ = mpc(x0, QuadCost(torch.diag_embed(Qd), q, torch.zeros(B, T, dtype=dt, device=dev)), d, d.jac,
+                      x_init=x0[:, None].repeat(1, T, 1).contiguous(), u_init=torch.full((B, T, nu), uh, dtype=dt, device=dev))
+        outs.append((x.cpu(), u.cpu(), list(mpc.last_newton_per_al)))
+    assert outs[0][2] == outs[1][2]
+    assert (outs[0][0] - outs[1][0]).abs().max() < 1e-5 and (outs[0][1] - outs[1][1]).abs().max() < 1e-5
