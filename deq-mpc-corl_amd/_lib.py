@@ -94,6 +94,8 @@ _SIGS = {
                                        C.POINTER(AlqpObstacles), _P, _P, C.c_double, _P]),
     "alqp_newton_step_ws": (C.c_int, [C.POINTER(AlqpDims), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P,
                                       C.c_long, C.c_long, _P, C.c_size_t, _P, _P, _P, _P]),
+    "alqp_newton_step_ws_obs": (C.c_int, [C.POINTER(AlqpDims), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P,
+                                          C.c_long, C.c_long, C.POINTER(AlqpObstacles), _P, C.c_size_t, _P, _P, _P, _P]),
     "alqp_merit_pick": (C.c_int, [C.POINTER(AlqpDims), C.c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P,
                                   C.c_long, C.c_long, C.POINTER(AlqpObstacles), _P, _P, _P, _P, _P, _P, _P]),
     "alqp_ipm_solve": (C.c_int, [C.POINTER(AlqpDims), C.POINTER(AlqpIpmParams), _P, _P, _P, _P, _P, _P, _P,

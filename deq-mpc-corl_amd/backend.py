@@ -303,16 +303,21 @@ class HipBackend:
         sfx = _dt(z)
         d = _lib.AlqpDims(B, T, nx, nu)
         if workspace is not None:
-            if obs is not None or factor is not None:
-                raise ValueError("mi_alqp: the quad Newton step takes neither obstacle rows nor a packed factor")
+            if factor is not None:
+                raise ValueError("mi_alqp: the quad Newton step leaves its factor in the workspace records (no packed factor)")
             need = self.workspace_bytes(*dims, dt)
             if workspace.numel() * workspace.element_size() < need:
                 raise ValueError("mi_alqp: workspace too small")
-            rc = getattr(self.lib, "alqp_newton_step_ws_" + sfx)(
-                C.byref(d), _ptr(z, "z", dt), _ptr(xnext, "xnext", dt), _ptr(F, "F", dt), _ptr(x0, "x0", dt),
-                _ptr(lam, "lam", dt), _ptr(rho, "rho", dt), _ptr(Qd, "Qd", dt), _ptr(q, "q", dt),
-                _ptr(ulo, "u_lower", dt), _ptr(uhi, "u_upper", dt), sb_u, st_u, _ptr(workspace, "workspace", dt), need,
-                _ptr(d_out, "d_out", dt), _ptr(g_out, "g_out", dt, True), _ptr(info, "info", torch.int32, True), _stream())
+            head = (C.byref(d), _ptr(z, "z", dt), _ptr(xnext, "xnext", dt), _ptr(F, "F", dt), _ptr(x0, "x0", dt),
+                    _ptr(lam, "lam", dt), _ptr(rho, "rho", dt), _ptr(Qd, "Qd", dt), _ptr(q, "q", dt),
+                    _ptr(ulo, "u_lower", dt), _ptr(uhi, "u_upper", dt), sb_u, st_u)
+            tail = (_ptr(workspace, "workspace", dt), need, _ptr(d_out, "d_out", dt), _ptr(g_out, "g_out", dt, True),
+                    _ptr(info, "info", torch.int32, True), _stream())
+            if obs is None:
+                rc = getattr(self.lib, "alqp_newton_step_ws_" + sfx)(*head, *tail)
+            else:   # obstacle rows / the state-estimator row set on the quad kernels
+                o = self._obs_struct(obs, dims, dt)
+                rc = getattr(self.lib, "alqp_newton_step_ws_obs_" + sfx)(*head, C.byref(o), *tail)
             _lib.check(rc, "alqp_newton_step_ws_" + sfx)
             self.last_step_kernel = "k_newton_step_quad"
             return

@@ -566,7 +566,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     const int b_raw = blockIdx.x * 16 + qi;
     const bool active = b_raw < a.B;
     const int b = active ? b_raw : a.B - 1;
-    const int T = a.T, M = C::M(T);
+    const int T = a.T, M = C::M(T) + T * a.nobs;   // obstacle rows behind each stage's bound rows
     Quad<real, NX, NU> qd;
     __shared__ real w_lds[QCfg<real, NX, NU>::WLDS_WORDS];   // fp64: the W panel (WPanel); one word otherwise
     qd.wl = w_lds + threadIdx.x;
@@ -588,6 +588,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     qd.dyn_h = 0;
     qd.rho = a.rho[b];
     qd.info = 0;
+    qd.nobs = a.nobs;
+    qd.gobs = a.nobs > 0 ? a.obs + (size_t)b * T * a.nobs * 3 : nullptr;
+    qd.obs_r2 = a.obs_r2;
+    qd.no_init = a.no_init != 0;
     // no copy-in: the forward sweep reads the caller's arrays itself and takes r_t = z_{t+1}[x] - xnext_t
     const real *gxn = a.xnext + (size_t)b * (T - 1) * NX;
     real *tg = (a.g_out && active) ? a.g_out + (size_t)b * T * N : nullptr;
@@ -1293,7 +1297,7 @@ int newton_step_impl(const AlqpDims *dims, const void *z, const void *xnext, con
     a.ulo = (const real *)u_lo; a.uhi = (const real *)u_hi; a.sb_u = sb_u; a.st_u = st_u;
     a.d_out = (real *)d_out; a.g_out = (real *)g_out; a.factor = (real *)factor_out; a.info = info;
     if (workspace) {   // quad variant: the factor stays in the workspace records (alqp_backward_ws)
-        if (a.nobs > 0 || a.no_init || factor_out) return ALQP_E_BADARG;
+        if (factor_out) return ALQP_E_BADARG;
         const size_t need = quad_ws_bytes<real>(dims->nx, dims->nu, dims->B, dims->T);
         if (need == 0) return ALQP_E_UNSUPPORTED;
         if (ws_bytes < need) return ALQP_E_BADARG;
@@ -1811,6 +1815,16 @@ ALQP_DEFINE_OBS(f64, double)
         if (!workspace) return ALQP_E_BADARG;                                                         \
         return alqp::newton_step_impl<REAL>(dims, z, xnext, F, x0, lam, rho, Qd, q, u_lo, u_hi, sb_u, \
                                             st_u, d_out, g_out, nullptr, info, stream, nullptr,       \
+                                            workspace, ws_bytes);                                     \
+    }                                                                                                 \
+    int alqp_newton_step_ws_obs_##SFX(const AlqpDims *dims, const void *z, const void *xnext, const void *F, \
+                                      const void *x0, const void *lam, const void *rho, const void *Qd, \
+                                      const void *q, const void *u_lo, const void *u_hi, long sb_u,   \
+                                      long st_u, const AlqpObstacles *obs, void *workspace, size_t ws_bytes, \
+                                      void *d_out, void *g_out, int *info, void *stream) {            \
+        if (!workspace) return ALQP_E_BADARG;                                                         \
+        return alqp::newton_step_impl<REAL>(dims, z, xnext, F, x0, lam, rho, Qd, q, u_lo, u_hi, sb_u, \
+                                            st_u, d_out, g_out, nullptr, info, stream, obs,           \
                                             workspace, ws_bytes);                                     \
     }
 #define ALQP_DEFINE_MERIT_PICK(SFX, REAL)                                                             \

@@ -254,6 +254,12 @@ struct Quad {
     }
     real *gFw;   // nonlinear fused solve: this instance's F_t linearisations (inside the workspace; gF points here too)
     real dyn_h;  //   step length of the dynamics model
+    // caller-mode step kernel only (forward<EXT = true>): obstacle rows (Obstacle_MPC, al_utils.py:313-323, 351-388; as in
+    // Team::forward_sweep) and the state-estimator variant's row set (al_utils_se.py:186-200, 300-310)
+    const real *gobs;   // this instance's sphere centres [T][nobs][3] (global memory), nullptr without obstacles
+    int nobs;
+    real obs_r2;
+    bool no_init;
 
     __device__ __forceinline__ real uhi(int t, int j) const { return guhi[t * st_u + j]; }
     __device__ __forceinline__ real ulo(int t, int j) const { return gulo[t * st_u + j]; }
@@ -409,7 +415,7 @@ struct Quad {
                 st_own_x(rp + C::oLE, vx);
                 {
                     const int ju = own_ju(), jc = ju < NU ? ju : 0;
-                    const real *lb = glam + T * NX + t * 2 * NU;
+                    const real *lb = glam + T * NX + t * (2 * NU + nobs);   // obstacle rows sit behind the stage's bound rows
                     const real a0 = lb[jc], a1 = lb[NU + jc], a2 = guhi[t * st_u + jc], a3 = gulo[t * st_u + jc];
                     const bool has = ju < NU;
                     gst4(rp + C::oUS + 4 * q, has ? a0 : real(0), has ? a1 : real(0), has ? a2 : real(0), has ? a3 : real(0));
@@ -652,7 +658,8 @@ struct Quad {
             }
 #pragma unroll
             for (int s = 0; s < SW; ++s) {
-                const bool valid = 4 * s + 3 < NX || 4 * s + q < NX;
+                bool valid = 4 * s + 3 < NX || 4 * s + q < NX;
+                if constexpr (EXT) valid = valid && !no_init;   // state estimator: no initial-state rows
                 const real r = valid ? z0[s] - xi[s] : real(0);
                 vpo[s] = valid ? fma_(rho, r, li[s]) : real(0);
                 if constexpr (C::PHI0_FWD) mdist += valid ? fma_(fma_(real(0.5) * rho, r, li[s]), r, real(0)) : real(0);  // initial-state rows
@@ -668,6 +675,7 @@ struct Quad {
             real dio[SY];   // diagonal of H_tt, own elements
             real v[SW];
             real zs[SY];
+            real hob[3] = {0, 0, 0};   // obstacle rows (EXT): rho J_k'J_k entries (row q, columns 0..2) of the active rows
             real *rp = recp(t);
             // ---- loads (one batch) + residual + multiplier estimate. Everything per-stage is read as OWN
             // elements (one or two instructions per vector) and z_t is then broadcast inside the quad: loads
@@ -689,7 +697,7 @@ struct Quad {
                     ld_own_ext<NX>(gz + (td + 1) * N, zn);
                     ld_own_ext<NX>(glam + td * NX, lm);
                     const int ju = own_ju(), jc = ju < NU ? ju : 0;
-                    const real *lb = glam + T * NX + t * 2 * NU;
+                    const real *lb = glam + T * NX + t * (2 * NU + nobs);   // obstacle rows sit behind the stage's bound rows
                     const bool has = ju < NU;
                     lu = has ? lb[jc] : real(0);
                     ll = has ? lb[NU + jc] : real(0);
@@ -762,9 +770,34 @@ struct Quad {
                     real d = Qo[m];
                     if constexpr (C::PHI0_FWD) mdist = fma_(fma_(real(0.5) * Qo[m], zs[m], qo[m]), zs[m], mdist);   // padding: 0
                     g += isx ? vpo[m < SW ? m : 0] : (isu ? gu : real(0));
-                    d += isx ? rho : (isu ? du : real(0));
+                    bool pinned = isx;
+                    if constexpr (EXT) {
+                        pinned = isx && !(no_init && t == 0);   // no E'E term on x_0 without initial-state rows
+                        if (no_init && isu) g = 0;              // the given controls carry no gradient (al_utils_se.py:300-310)
+                    }
+                    d += pinned ? rho : (isu ? du : real(0));
                     dio[m] = d;
                     go[m] = g;
+                }
+                if constexpr (EXT && NX >= 3) {
+                    if (nobs > 0) {
+                        // J_k = -2 (p - o_k)' on x_t[0:3]: g += (lam_k + rho max(c_k, 0)) J_k', and for the rows with
+                        // c_k >= 0 the Gauss-Newton term rho J_k'J_k on the position corner (al_utils.py:373-386, 113-120)
+                        const real *lk = glam + T * NX + t * (2 * NU + nobs) + 2 * NU;
+                        real gob = 0;
+                        for (int k = 0; k < nobs; ++k) {
+                            const real *o = gobs + (size_t)(t * nobs + k) * 3;
+                            const real d0 = zt[0] - o[0], d1 = zt[1] - o[1], d2 = zt[2] - o[2];
+                            const real ck = obs_r2 - fma_(d0, d0, fma_(d1, d1, d2 * d2));
+                            const real dh = q == 0 ? d0 : (q == 1 ? d1 : d2);
+                            gob = fma_(fma_(rho, ck > 0 ? ck : real(0), lk[k]), real(-2) * dh, gob);
+                            if (ck >= 0) {
+                                const real w4 = real(4) * rho * dh;
+                                hob[0] = fma_(w4, d0, hob[0]); hob[1] = fma_(w4, d1, hob[1]); hob[2] = fma_(w4, d2, hob[2]);
+                            }
+                        }
+                        go[0] += q < 3 ? gob : real(0);   // rows 0..2 of stage t are element slot 0 of lanes 0..2
+                    }
                 }
                 // Y_j = -(g_j) - (W y)_{t-1,j}: broadcast of the own part plus the quad-reduced F'v term
 #pragma unroll
@@ -804,6 +837,12 @@ struct Quad {
 #pragma unroll
                 for (int c = 0; c < 4; ++c)
                     if (4 * s + c < N) H[C::hidx(s, 4 * s + c)] = (q == c) ? dio[s] : real(0);
+            if constexpr (EXT && NX >= 3) {
+                if (nobs > 0 && q < 3) {
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) H[C::hidx(0, j)] += hob[j];
+                }
+            }
             // minus the Schur complement of stage t-1 (its registers are dead afterwards: keeps
             // the F'F phase below within the 256 architectural VGPRs)
             if (t > 0) {

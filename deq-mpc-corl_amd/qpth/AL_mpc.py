@@ -516,14 +516,14 @@ class MPC(Module):
         while steps < MAX_NEWTON:
             steps += 1
             xn, F = self._linearize(st, z)
-            # from B = QUAD_MIN_BATCH on (and without obstacle rows) the direction comes from the quad kernels,
+            # from B = QUAD_MIN_BATCH on the direction comes from the quad kernels,
             # whose factor stays in the workspace records: a private one (ws["qws"]) when backward follows
             qws = ws.get("qws")
-            if qws is None and not okw and hasattr(be, "_workspace") and B >= getattr(be, "QUAD_MIN_BATCH", 1 << 62):
+            if qws is None and hasattr(be, "_workspace") and B >= getattr(be, "QUAD_MIN_BATCH", 1 << 62):
                 qws = be._workspace(dims, z)[0]
-            if qws is not None:
+            if qws is not None:   # (obstacle rows / the state-estimator row set included: alqp_newton_step_ws_obs)
                 be.newton_step(dims, z, xn, F, st.x0, st.lam, st.rho, Qd, q, lo, hi, sb, stt, ws["d"],
-                               info=ws["info"], workspace=qws)
+                               info=ws["info"], workspace=qws, **okw)
             else:
                 be.newton_step(dims, z, xn, F, st.x0, st.lam, st.rho, Qd, q, lo, hi, sb, stt, ws["d"],
                                factor=ws.get("factor") if need_factor else None, info=ws["info"], **okw)
@@ -571,8 +571,9 @@ class MPC(Module):
             raise RuntimeError("MPC: the linearize_once streaming route is not differentiable (the reference's "
                                "al_utils_lin.NewtonAL.backward returns an incorrect number of gradients)")
         has_obs = self._has_extra_rows()
-        use_qws = need_grad and hasattr(be, "backward_ws") and B >= getattr(be, "QUAD_MIN_BATCH", 0) and (
-            lin is not None or not has_obs) and not (bool(self.linearize_once) and st.stream_mode)
+        # (round 3: the quad step kernel takes the obstacle / state-estimator rows too, so their factor can stay in its records)
+        use_qws = need_grad and hasattr(be, "backward_ws") and B >= getattr(be, "QUAD_MIN_BATCH", 0) and not (
+            bool(self.linearize_once) and st.stream_mode)
         if use_qws:
             ws["qws"] = be.new_workspace(dims, st.z)
         elif need_grad:

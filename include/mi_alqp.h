@@ -339,6 +339,16 @@ int alqp_solve_nonlin_f64(const AlqpDims *dims, const AlqpParams *prm, int dyn_i
  * with PyTorch-coded dynamics); arguments as their plain twins. nx >= 3 required.
  */
 
+/* The quad-variant Newton step (alqp_newton_step_ws: 16 instances per wavefront, factor left in the workspace records for
+ * alqp_backward_ws) with the same extra rows: what Obstacle_MPC and the state-estimator variant run at B >= 4096. */
+int alqp_newton_step_ws_obs_f32(const AlqpDims *dims, const void *z, const void *xnext, const void *F,
+                                const void *x0, const void *lam, const void *rho, const void *Qd, const void *q,
+                                const void *u_lo, const void *u_hi, long sb_u, long st_u, const AlqpObstacles *obs,
+                                void *workspace, size_t ws_bytes, void *d_out, void *g_out, int *info, void *stream);
+int alqp_newton_step_ws_obs_f64(const AlqpDims *dims, const void *z, const void *xnext, const void *F,
+                                const void *x0, const void *lam, const void *rho, const void *Qd, const void *q,
+                                const void *u_lo, const void *u_hi, long sb_u, long st_u, const AlqpObstacles *obs,
+                                void *workspace, size_t ws_bytes, void *d_out, void *g_out, int *info, void *stream);
 int alqp_newton_step_obs_f32(const AlqpDims *dims, const void *z, const void *xnext, const void *F,
                              const void *x0, const void *lam, const void *rho, const void *Qd, const void *q,
                              const void *u_lo, const void *u_hi, long sb_u, long st_u, const AlqpObstacles *obs,

@@ -148,3 +148,42 @@ def test_nonlinear_caller_mode_quad_route_equals_team_route(with_grad):
     if with_grad:
         for ga, gb in zip(a[4], b[4]):
             assert float((ga - gb).abs().max()) < 1e-6 * float(gb.abs().max())
+
+
+@pytest.mark.parametrize("dims", [(40, 20, 13, 4), (33, 10, 8, 2), (4096, 20, 13, 4)])
+@pytest.mark.parametrize("dtype,tol", [(torch.float64, 1e-9), (torch.float32, 2e-3)])
+@pytest.mark.parametrize("rows", ["obstacles", "state_estimator"])
+def test_newton_step_quad_with_extra_rows_equals_team(dims, dtype, tol, rows):
+    """Obstacle rows (Obstacle_MPC, al_utils.py:313-323, 351-388) and the state-estimator row set on the quad step
+    kernel (alqp_newton_step_ws_obs) against the team step kernel that the reference fixtures pin
+    (tests/test_obstacles_golden.py, test_state_estimator_golden.py): ragged batches and the B = 4096 the class switches at."""
+    from deq_mpc_corl_amd.backend import default_backend
+    be = default_backend()
+    B, T, nx, nu = dims
+    p, z, xn, lam, rho = _problem(B, T, nx, nu, dtype, active=True)
+    if rows == "obstacles":
+        nobs = 4
+        g = torch.Generator(device="cpu").manual_seed(11)
+        # spheres around the trajectory's positions: about a third of the rows active (c_k >= 0)
+        pos = (z[:, :, None, :3].cpu().double() + 0.25 * torch.randn(B, T, nobs, 3, generator=g, dtype=torch.float64)).to(dtype).to(DEV).contiguous()
+        obs = (pos, 0.3)
+        lam_o = (0.2 * torch.rand(B, T, nobs, generator=g, dtype=torch.float64)).to(dtype).to(DEV)
+        lam = torch.cat([lam[:, :T * nx], torch.cat([lam[:, T * nx:].reshape(B, T, 2 * nu), lam_o], 2).reshape(B, -1)], 1).contiguous()
+    else:
+        obs = "state_estimator"
+    out = {}
+    for variant in ("team", "quad"):
+        d = torch.empty_like(z)
+        g_ = torch.empty_like(z)
+        info = torch.zeros(B, dtype=torch.int32, device=DEV)
+        ws = be.new_workspace(dims, z) if variant == "quad" else None
+        be.newton_step(dims, z, xn, p.F, p.x0, lam, rho, p.Qd, p.q, p.u_lo, p.u_hi, 0, 0, d, g_out=g_, info=info, obs=obs,
+                       workspace=ws)
+        torch.cuda.synchronize()
+        assert int(info.abs().max()) == 0
+        out[variant] = (d.cpu().numpy(), g_.cpu().numpy())
+    scale = max(1.0, float(np.abs(out["team"][0]).max()))
+    assert np.abs(out["quad"][1] - out["team"][1]).max() < tol * max(1.0, float(np.abs(out["team"][1]).max()))
+    assert np.abs(out["quad"][0] - out["team"][0]).max() < tol * scale
+    if rows == "state_estimator":
+        assert np.abs(out["quad"][0][..., nx:]).max() < tol * scale      # du = 0: the controls are given

@@ -131,10 +131,25 @@ def test_obstacle_mpc_host_logic_cpu(name):
     _replay(name, OracleBackend(), "cpu")
 
 
+def _hip_backend(route):
+    """route "quad": every Newton direction through the quad step kernel (alqp_newton_step_ws_obs: what the class takes by
+    itself from B = 4096 on), the factor in its workspace records for backward_ws; "team": the small-batch default."""
+    from deq_mpc_corl_amd.backend import HipBackend
+    be = HipBackend()
+    if route == "quad":
+        be.QUAD_MIN_BATCH = 1
+    return be
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("name", OBS)
-def test_obstacle_mpc_hip(name):
-    _replay(name, None, "cuda:0")
+@pytest.mark.parametrize("route", ["team", "quad"])
+def test_obstacle_mpc_hip(name, route):
+    """The reference-generated obstacle fixtures (Newton counts, lamda incl. the obstacle rows, rho, x, u, gradients, the
+    streaming call) on both step kernels."""
+    be = _hip_backend(route)
+    _replay(name, be, "cuda:0")
+    assert be.last_step_kernel == ("k_newton_step_quad" if route == "quad" else "k_newton_step")
 
 
 @pytest.mark.gpu

@@ -92,8 +92,15 @@ def test_state_estimator_host_logic_cpu(name):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("name", SE)
-def test_state_estimator_hip(name):
-    _replay(name, None, "cuda:0")
+@pytest.mark.parametrize("route", ["team", "quad"])
+def test_state_estimator_hip(name, route):
+    """route "quad": the state-estimator row set on the quad step kernel (alqp_newton_step_ws_obs, what B >= 4096 takes)."""
+    from deq_mpc_corl_amd.backend import HipBackend
+    be = HipBackend()
+    if route == "quad":
+        be.QUAD_MIN_BATCH = 1
+    _replay(name, be, "cuda:0")
+    assert be.last_step_kernel == ("k_newton_step_quad" if route == "quad" else "k_newton_step")
 
 
 def test_state_estimator_rejects_affine_lindx():
