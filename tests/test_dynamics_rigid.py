@@ -88,7 +88,8 @@ def test_rigid_provider_kernel_vs_restatement(model, dtype, tol, K):
     xd, ud = x.to("cuda:0", dtype), u.to("cuda:0", dtype)
     xn = dyn(xd, ud)
     xn2, (A, B) = dyn.jac(xd, ud)
-    assert torch.equal(xn, xn2)
+    # (value-only launch and value + tangents launch: the same formulas, contracted differently by the compiler)
+    assert (xn - xn2).abs().max() <= (1e-13 if dtype == torch.float64 else 1e-5) * max(1.0, float(xn.abs().max()))
     ref = rp.step(P, x, u)
     scale = max(1.0, float(ref.abs().max()))
     assert (xn.cpu().double() - ref).abs().max() < tol * scale

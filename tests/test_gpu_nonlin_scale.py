@@ -171,6 +171,9 @@ def test_newton_step_quad_with_extra_rows_equals_team(dims, dtype, tol, rows):
         lam = torch.cat([lam[:, :T * nx], torch.cat([lam[:, T * nx:].reshape(B, T, 2 * nu), lam_o], 2).reshape(B, -1)], 1).contiguous()
     else:
         obs = "state_estimator"
+        F = p.F.clone()
+        F[..., nx:] = 0        # as the host class prepares it: the control Jacobian is multiplied by 0 (al_utils_se.py:151)
+        p = p._replace(F=F.contiguous())
     out = {}
     for variant in ("team", "quad"):
         d = torch.empty_like(z)
