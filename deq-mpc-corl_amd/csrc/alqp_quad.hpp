@@ -415,7 +415,7 @@ struct Quad {
                 st_own_x(rp + C::oLE, vx);
                 {
                     const int ju = own_ju(), jc = ju < NU ? ju : 0;
-                    const real *lb = glam + T * NX + t * (2 * NU + nobs);   // obstacle rows sit behind the stage's bound rows
+                    const real *lb = glam + T * NX + t * 2 * NU;
                     const real a0 = lb[jc], a1 = lb[NU + jc], a2 = guhi[t * st_u + jc], a3 = gulo[t * st_u + jc];
                     const bool has = ju < NU;
                     gst4(rp + C::oUS + 4 * q, has ? a0 : real(0), has ? a1 : real(0), has ? a2 : real(0), has ? a3 : real(0));
