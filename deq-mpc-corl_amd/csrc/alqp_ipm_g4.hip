@@ -32,7 +32,10 @@ constexpr int kSlots = 5;   // stage slots per lane group: T <= 4 * kSlots
 // Waves per SIMD the register allocation aims at: fp64 is LDS-limited to three workgroups per CU at (20,13,4) (53 KB
 // each), one wavefront per SIMD with the whole register file; fp32 images are half the size (six per CU), so the
 // kernel is held to 256 registers and two wavefronts share a SIMD and hide each other's LDS and DPP latencies.
-template <typename real> constexpr int kWavesPerSimd = sizeof(real) == 4 ? 2 : 1;
+#ifndef ALQP_G4_F32_WAVES
+#define ALQP_G4_F32_WAVES 2
+#endif
+template <typename real> constexpr int kWavesPerSimd = sizeof(real) == 4 ? ALQP_G4_F32_WAVES : 1;
 
 template <typename real, int NX, int NU>
 __global__ __launch_bounds__(64, kWavesPerSimd<real>) void k_ipm_g4(const IpmArgs<real> a) {

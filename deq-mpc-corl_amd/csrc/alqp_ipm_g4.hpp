@@ -10,11 +10,14 @@
 //       upper-bound rows (s, z), quarter 1 (r = 4+j): lower-bound rows, quarter 2 (r = 8+j): the control u_j;
 //   * F (both orientations are needed: F x and F'y), the factor of the Schur complement (unit-lower inverse
 //     M_m = L_m^-1 of S~_m = L D L', packed, + 1/D) and one staging vector in LDS.
-// The stage-local phases (residuals, K products, right-hand sides, outputs) run on all four groups at once;
-// the horizon-sequential phases (block factorisation, the two substitution sweeps) run redundantly on the
-// four groups - a 16-lane row is the unit of the v_fmac_*_dpp row_newbcast mat-vec: lane r holds row r of the
-// matrix, the vector is spread over the row, one instruction per column. HBM traffic: inputs once, the best
-// iterate when it improves.
+// The stage-local phases (residuals, K products, right-hand sides, outputs) run on all four groups at once.
+// The horizon-sequential phases (block factorisation, substitution sweeps) are TWISTED: the block-tridiagonal
+// Schur complement is eliminated from both ends towards the middle block - the same arithmetic as one pass from
+// the top, half the sequential depth. Lanes 0-31 run the chain that starts at block 0, lanes 32-63 the chain
+// that starts at block T-1, in ONE instruction stream (only LDS addresses and a few selects differ per half);
+// inside a half the two groups work redundantly - a 16-lane row is the unit of the v_fmac_*_dpp row_newbcast
+// mat-vec: lane r holds row r of the matrix, the vector is spread over the row, one instruction per column.
+// HBM traffic: inputs once, the best iterate when it improves.
 //
 // Internal conventions: the multiplier block m (m = 0..T-1) belongs to the constraint that defines x_m:
 //   c_m(x) = F_{m-1} x_{m-1} - x_m[:nx] + fh_m,  fh_m = f_{m-1} (m >= 1), fh_0 = x0, F_{-1} = 0
@@ -22,10 +25,15 @@
 // (so that every block has the same form; the sign is applied when vectors are read / written in the
 // reference's order). Schur complement S = A Phi^-1 A' + eps:
 //   S_mm = F_{m-1} P_{m-1} F_{m-1}' + P_{m,x} + eps,   S_{m,m-1} = -F_{m-1}[:, :nx] diag(P_{m-1,x})
-// Block elimination with S~_m = S_mm - S_{m,m-1} S~_{m-1}^-1 S_{m,m-1}', S~_m^-1 = M_m' D_m^-1 M_m:
-//   forward  v'_m = v_m + A_{m-1} (P_x o p_{m-1}),  p_m = S~_m^-1 v'_m
-//   backward x_m  = p_m + S~_m^-1 (P_x o (A_m' x_{m+1}))
-// The sub-diagonal factor block is never stored (A_m is in LDS anyway): three mat-vecs per stage and sweep.
+// Block elimination, S~_m^-1 = M_m' D_m^-1 M_m (A_m = F_m[:, :nx], P_m = P_{m,x}), mid = T / 2:
+//   top chain    m = 0 .. mid-1:    S~_m = S_mm - S_{m,m-1} S~_{m-1}^-1 S_{m,m-1}',  v'_m = v_m + A_{m-1} (P_{m-1} o p_{m-1})
+//   bottom chain m = T-1 .. mid+1:  S~_m = S_mm - S_{m+1,m}' S~_{m+1}^-1 S_{m+1,m},  v'_m = v_m + P_m o (A_m' p_{m+1})
+//   (p_m = S~_m^-1 v'_m); the middle block takes both corrections; then outwards from y_mid = p_mid:
+//   top  y_m = p_m + S~_m^-1 (P_m o (A_m' y_{m+1})),   bottom  y_m = p_m + S~_m^-1 (A_{m-1} (P_{m-1} o y_{m-1}))
+// The off-diagonal factor blocks are never stored (A_m is in LDS anyway): three mat-vecs per block and direction.
+// LDS order of the blocks: F_t at slot t (t < mid) or mid + T-2-t (the bottom chain walks its blocks in
+// ascending addresses too); factor blocks: top chain and the middle at slots 0 .. mid, bottom chain at slots
+// mid+1 .. T-1 in the order it produces them - step i of either chain is (per-lane base) + i * (block size).
 //
 // The file is written against a small execution policy X (per-lane value types V / VI / VM and the cross-lane
 // and memory primitives) so that the SAME source runs on the GPU (alqp_ipm_g4_gpu.hpp: V = real, DPP asm)
@@ -147,6 +155,24 @@ struct Solver {
     G4_FN VM mU() const { return (qd == 2) & (j < NU); }
     G4_FN VM g0() const { return lane < 16; }
     G4_FN V sgn() const { return X::sel(qd == 0, X::splat(real(1)), X::splat(real(-1))); }
+    static G4_FN VM um(bool c) { return X::splati(c ? 1 : 0) != 0; }   // a uniform condition as a lane mask
+
+    // The two elimination chains: top = blocks 0 .. mid-1 (lanes 0-31), bottom = blocks T-1 .. mid+1 (lanes 32-63,
+    // starting dl = 0 or 1 steps late so that both arrive at the middle block after `steps` steps).
+    struct Twist { int mid, dl, steps, MB0; };
+    G4_FN Twist twist() const {
+        Twist w;
+        w.mid = T / 2;
+        w.dl = w.mid - (T - 1 - w.mid);
+        w.steps = w.mid;
+        w.MB0 = w.mid + 1 - w.dl;   // factor slot of the bottom chain's step i: MB0 + i
+        return w;
+    }
+    G4_FN VM bottom() const { return lane >= 32; }
+    G4_FN VI slotF(const VI &t) const {   // LDS slot of F_t
+        const int mid = T / 2;
+        return X::seli(t < mid, t, X::splati(mid + T - 2) - t);
+    }
 
     G4_FN VI tof(int i) const { return g + 4 * i; }
     G4_FN VM vs(int i) const { return tof(i) < T; }
@@ -193,7 +219,7 @@ struct Solver {
             const VM ok = idx < tot;
             const VI t = idx / FSZ;
             const VI el = idx - t * FSZ;
-            X::lds_st(sF, idx, X::g_ld(Fg, t * sFt + el, ok), ok);
+            X::lds_st(sF, slotF(t) * FSZ + el, X::g_ld(Fg, t * sFt + el, ok), ok);
         }
         G4_UNROLL
         for (int i = 0; i < SL; ++i) {
@@ -205,7 +231,7 @@ struct Solver {
         }
         hq = zero();
         if (a.uhi && a.ulo) hq = X::g_ld(a.uhi, j, mQ() & (qd == 0)) - X::g_ld(a.ulo, j, mQ() & (qd == 1));
-        X::lds_st(sM, lane * MSZ + ZC, zero(), lane < T);   // the zero cells of every stage's factor block
+        X::lds_st(sM, lane * MSZ + ZC, zero(), lane < T);   // the zero cell of every factor slot
         X::fence();
         tick(0);
     }
@@ -257,7 +283,7 @@ struct Solver {
         for (int i = 0; i < SL; ++i) {
             const VI t = tof(i);
             const VI tm = X::mini(X::maxi(t - 1, X::splati(0)), X::splati(T - 2));
-            const VI base = tm * FSZ + rc * N;
+            const VI base = slotF(tm) * FSZ + rc * N;
             V fr[N];
             G4_UNROLL
             for (int k = 0; k < N; ++k) fr[k] = X::lds_ld(sF, base + k);
@@ -273,7 +299,8 @@ struct Solver {
         for (int i = 0; i < SL; ++i) {
             const VI t = tof(i);
             const VI tc = X::mini(t, X::splati(T - 2));
-            const VI bx = tc * FSZ + rc, bu = tc * FSZ + NX + j;
+            const VI sb = slotF(tc) * FSZ;
+            const VI bx = sb + rc, bu = sb + NX + j;
             V fc[NX];
             G4_UNROLL
             for (int q = 0; q < NX; ++q) fc[q] = X::lds_ld(sF, bx + q * N);
@@ -332,11 +359,15 @@ struct Solver {
     static G4_FN real sqrt_(double v) { return sqrt(v); }
 
     // ---- factorisation at the current (s, z) ----------------------------------------------------------
-    // Per block m (lane r = row r of every 13 x 13 matrix, all four groups alike):
-    //   S = F P F' + P_x + eps  -  Z D^-1 Z',   Z = S_{m,m-1} M_{m-1}'   (rank-1 updates of the row set: X::multi)
+    // Per step both chains take one block each (lane r = row r of every 13 x 13 matrix; the two groups of a half alike):
+    //   S = F P F' + P_x + eps  -  Z D^-1 Z',   Z = (coupling to the chain's previous block) M_prev'
+    //       top: Z[r][c] = -sum_k A_{m-1}[r][k] P_{m-1}[k] M_{m-1}[c][k]; bottom: -sum_k P_m[r] A_m[k][r] M_{m+1}[c][k]
+    //       (rank-1 updates of the row set, X::multi, with the previous block's M rows still in registers)
     //   S = L D L' and M = L^-1 in ONE pivot loop: the row operation that eliminates column C of S is applied to an
     //   identity alongside (X::self), so M's rows come out on the lanes that own them - no separate triangular inversion
-    //   with its dependent chains - and stay in registers for the next block's Z.
+    //   with its dependent chains.
+    // The last step is the middle block: the top half forms P_x + eps + F P F' - Z D^-1 Z', the bottom half only its
+    // - Z D^-1 Z'; the halves exchange and add, and both factor the same matrix.
     G4_FN void factor() {
         refresh();
         G4_UNROLL
@@ -347,54 +378,81 @@ struct Solver {
         }
         X::fence();
         tick(2);
-        V Mrow[NX];      // row r of M_{m-1} (unit lower: Mrow[k] = M[r][k] for k < r, 1 at k = r, 0 beyond)
-        V dprev[NX];     // 1 / d_k of block m-1 (uniform)
+        const Twist tw = twist();
+        V Mrow[NX];      // row r of the chain's previous M (unit lower: Mrow[k] = M[r][k] for k < r, 1 at k = r, 0 beyond)
+        V dprev[NX];     // 1 / d_k of that block (uniform inside a half)
         G4_UNROLL
         for (int k = 0; k < NX; ++k) { Mrow[k] = zero(); dprev[k] = zero(); }
-        for (int m = 0; m < T; ++m) {
-            real *Mm = sM + (long)m * MSZ;
+        for (int i = 0; i <= tw.steps; ++i) {
+            const bool is_mid = i == tw.steps;
+            const VM bot = bottom();
+            const int mb_ = T - 1 + tw.dl - i;                                // the bottom chain's block (T: not started yet)
+            const VI mv = X::seli(bot, X::splati(mb_), X::splati(i));
+            const VM live = !bot | um(i >= tw.dl);
+            const VM base = !bot | um(!is_mid);                               // who adds P_x + eps + F P F'
+            const V pxo = X::lds_ld(sPx, X::seli(bot, X::splati((mb_ < T ? mb_ : T - 1) * NX), X::splati(i * NX)) + rc);
             V S[NX];
-            const V pm = X::lds_ld(sPx, rc + m * NX) + e;
             G4_UNROLL
-            for (int c = 0; c < NX; ++c) S[c] = keep(r == c, pm);
-            if (m > 0) {
-                const int t = m - 1;
-                const VI base = rc * N + t * FSZ;
-                V fr[N], fp[N];
+            for (int c = 0; c < NX; ++c) S[c] = keep((r == c) & base, pxo + e);
+            // rows of F_{m-1} (none for block 0), scaled by P_{m-1}
+            const int st = i > 0 ? i - 1 : 0;
+            const int sbt = tw.mid - tw.dl + i < T - 2 ? tw.mid - tw.dl + i : T - 2;
+            const VI fb = X::seli(bot, X::splati(sbt * FSZ), X::splati(st * FSZ)) + rc * N;
+            const VI pblk = X::seli(bot, X::splati(mb_ - 1), X::splati(st));
+            const VM f_ok = base & live & (mv > 0);
+            V fr[N], fp[N];
+            G4_UNROLL
+            for (int k = 0; k < N; ++k) {
+                fr[k] = keep(f_ok, X::lds_ld(sF, fb + k));
+                fp[k] = fr[k] * (k < NX ? X::lds_ld(sPx, pblk * NX + k) : X::lds_ld(sPu, pblk * 4 + (k - NX)));
+            }
+            G4_UNROLL
+            for (int k = 0; k < N; ++k) fmac_multi<X, 0, NX>(S, fr[k], fp[k]);   // F P F'
+            tick(11);
+            // coupling rows: top fp[c] = A_{m-1}[r][c] P_{m-1}[c]; bottom P_m[r] A_m[c][r] (column r of A_m; none for block T-1)
+            int zs = tw.mid + i - tw.dl - 1;
+            zs = zs < 0 ? 0 : (zs > T - 2 ? T - 2 : zs);
+            const VM zb_ok = bot & live & (mv < T - 1);
+            const VI zb = X::splati(zs * FSZ) + rc;
+            V zsrc[NX], Z[NX], zd[NX];
+            G4_UNROLL
+            for (int c = 0; c < NX; ++c) {
+                zsrc[c] = X::sel(bot, keep(zb_ok, X::lds_ld(sF, zb + c * N) * pxo), fp[c]);
+                Z[c] = zsrc[c];
+            }
+            z_rows<0>(Z, Mrow, zsrc);   // Z[r][c] = -(zsrc[c] + sum_{k<c} M[c][k] zsrc[k]), M[c][k] = lane c's Mrow[k]
+            G4_UNROLL
+            for (int c = 0; c < NX; ++c) { zd[c] = Z[c] * dprev[c]; Z[c] = -Z[c]; }
+            tick(12);
+            G4_UNROLL
+            for (int k = 0; k < NX; ++k) fmac_multi<X, 0, NX>(S, Z[k], zd[k]);   // S -= Z D^-1 Z'
+            tick(13);
+            if (is_mid) {
+                const VI other = (lane + 32) & 63;
                 G4_UNROLL
-                for (int k = 0; k < N; ++k) {
-                    fr[k] = X::lds_ld(sF, base + k);
-                    fp[k] = fr[k] * (k < NX ? X::lds_ldu(sPx, t * NX + k) : X::lds_ldu(sPu, t * 4 + (k - NX)));
-                }
-                G4_UNROLL
-                for (int k = 0; k < N; ++k) fmac_multi<X, 0, NX>(S, fr[k], fp[k]);   // F P F'
-                tick(11);
-                // Z[r][c] = -(fp[c] + sum_{k<c} M[c][k] fp[k]), M[c][k] = lane c's Mrow[k]
-                V Z[NX], zd[NX];
-                G4_UNROLL
-                for (int c = 0; c < NX; ++c) Z[c] = fp[c];
-                z_rows<0>(Z, Mrow, fp);
-                G4_UNROLL
-                for (int c = 0; c < NX; ++c) { zd[c] = Z[c] * dprev[c]; Z[c] = -Z[c]; }
-                tick(12);
-                G4_UNROLL
-                for (int k = 0; k < NX; ++k) fmac_multi<X, 0, NX>(S, Z[k], zd[k]);   // S -= Z D^-1 Z'
-                tick(13);
+                for (int c = 0; c < NX; ++c) S[c] = S[c] + X::gather(S[c], other);
             }
             G4_UNROLL
             for (int k = 0; k < NX; ++k) Mrow[k] = keep(r == k, X::splat(real(1)));
-            ldl<0>(S, Mrow, dprev, m);
+            ldl<0>(S, Mrow, dprev, mv, live);
+            if (i < tw.dl) {   // the bottom chain has not started: it has no previous block
+                G4_UNROLL
+                for (int k = 0; k < NX; ++k) { Mrow[k] = keep(!bot, Mrow[k]); dprev[k] = keep(!bot, dprev[k]); }
+            }
             tick(14);
+            const VI mo = X::seli(bot, X::splati((tw.MB0 + i) * MSZ), X::splati(i * MSZ));
+            const VM st_ok = ((lane & 16) == 0) & mXr() & live & (!bot | um(!is_mid));
             G4_UNROLL
-            for (int k = 0; k + 1 < NX; ++k) X::lds_st(Mm, ((rc * (rc - 1)) >> 1) + k, Mrow[k], g0() & (r > k) & mXr());
-            X::lds_st(Mm, r + NXL, dlane(dprev), g0() & mXr());
+            for (int k = 0; k + 1 < NX; ++k) X::lds_st(sM, mo + (((rc * (rc - 1)) >> 1) + k), Mrow[k], st_ok & (r > k));
+            X::lds_st(sM, mo + (r + NXL), dlane(dprev), st_ok);
             X::fence();
             tick(15);
         }
-        info = X::firsti(infov);
+        const int it = X::firsti(infov), ib = X::lanei(infov, 32);
+        info = it ? it : ib;
         tick(3);
     }
-    // Z[c] += sum_{k<c} bcast_c(Mrow[k]) * fp[k], as rank-1 updates over k (entries with c <= k are zero and skipped)
+    // Z[c] += sum_{k<c} bcast_c(Mrow[k]) * src[k], as rank-1 updates over k (entries with c <= k are zero and skipped)
     template <int K>
     G4_FN void z_rows(V *Z, const V *Mrow, const V *fp) const {
         if constexpr (K + 1 < NX) {
@@ -413,57 +471,87 @@ struct Solver {
     // L[r][C] = S[r][C] / d for r > C; the row operation row_r -= L[r][C] row_C on the trailing columns of S and on the
     // leading columns of the identity that becomes M = L^-1
     template <int C>
-    G4_FN void ldl(V *S, V *Mrow, V *dinv, int m) {
+    G4_FN void ldl(V *S, V *Mrow, V *dinv, const VI &mv, const VM &live) {
         if constexpr (C < NX) {
             const V d = X::template bcast<C>(S[C]);
-            infov = X::seli((infov == 0) & !(d > zero()), X::splati(m * NX + C + 1), infov);
+            infov = X::seli((infov == 0) & live & !(d > zero()), mv * NX + (C + 1), infov);
             const V di = X::rcp(X::absv(d));
             dinv[C] = di;
             const V nl = keep(r > C, -(S[C] * di));
             fmac_multi<X, C + 1, NX - 1 - C>(S + C + 1, S[C], nl);   // S[r][k] -= L[r][C] * S[k][C], k > C
             if constexpr (C + 1 < NX) X::template self<C, C + 1>(Mrow, nl);   // M[r][k] -= L[r][C] * M[C][k], k <= C
-            ldl<C + 1>(S, Mrow, dinv, m);
+            ldl<C + 1>(S, Mrow, dinv, mv, live);
         }
     }
 
-    // S~_m^-1 v = M' (D^-1 (M v)) with the packed factor block of stage m
-    struct MOff { VI R[NX], C[NX]; };   // packed-M offsets of (r, k), k < r, and of (k, r), k > r; the zero cell otherwise
-    G4_FN void m_offsets(MOff &o) const {
+    // Per-lane word offsets of a sweep step's operands, relative to (uniform) step * block size: packed-M cells (r, k),
+    // k < r / (k, r), k > r (the slot's zero cell otherwise), 1/d_r, and the 13 entries of the A operand - row r of
+    // A (entries k) or column r (entries k * N apart), whichever the half's chain needs in the current direction.
+    struct SweepIdx { VI R[NX], C[NX], D, A[NX]; };
+    G4_FN void m_offsets(SweepIdx &o, const Twist &tw) const {
+        const VI hb = X::seli(bottom(), X::splati(tw.MB0 * MSZ), X::splati(0));
         G4_UNROLL
         for (int k = 0; k < NX; ++k) {
-            o.R[k] = X::seli((r > k) & mXr(), ((rc * (rc - 1)) >> 1) + k, X::splati(ZC));
-            o.C[k] = X::seli((r < k) & mXr(), X::splati(k * (k - 1) / 2) + rc, X::splati(ZC));
+            o.R[k] = hb + X::seli((r > k) & mXr(), ((rc * (rc - 1)) >> 1) + k, X::splati(ZC));
+            o.C[k] = hb + X::seli((r < k) & mXr(), X::splati(k * (k - 1) / 2) + rc, X::splati(ZC));
         }
+        o.D = hb + rc + NXL;
     }
-    // Operands of one sweep stage, loaded from LDS one stage AHEAD of their use (two sets, ping-pong): a wavefront is
-    // alone on its SIMD, so nothing else hides the LDS latency of a stage's ~40 matrix reads.
+    // inwards: top rows of A_{i-1}, bottom columns of A_m (m = T-1+dl-i, slot mid + i - dl - 1)
+    G4_FN void a_offsets_in(SweepIdx &o, const Twist &tw) const {
+        G4_UNROLL
+        for (int k = 0; k < NX; ++k)
+            o.A[k] = X::seli(bottom(), X::splati((tw.mid - tw.dl - 1) * FSZ + k * N) + rc, rc * N + (k - FSZ));
+    }
+    // outwards: top columns of A_i, bottom rows of A_{m-1} (slot mid + i - dl)
+    G4_FN void a_offsets_out(SweepIdx &o, const Twist &tw) const {
+        G4_UNROLL
+        for (int k = 0; k < NX; ++k)
+            o.A[k] = X::seli(bottom(), X::splati((tw.mid - tw.dl) * FSZ + k) + rc * N, X::splati(k * N) + rc);
+    }
+    // Operands of one sweep step, loaded from LDS one step AHEAD of their use (two sets, ping-pong): a wavefront is
+    // alone on its SIMD, so nothing else hides the LDS latency of a step's ~40 matrix reads.
     static constexpr int NM = NX > 1 ? NX - 1 : 1;
-    struct SweepOps { V a[NX], mr[NM], mc[NM], di, px, v; };
-    G4_FN void load_factor(int m, SweepOps &o, const MOff &mo) const {
-        const real *Mm = sM + (long)m * MSZ;
+    struct SweepOps { V a[NX], mr[NM], mc[NM], di, pa, pb, v; VI vi; };
+    G4_FN void load_factor(int i, SweepOps &o, const SweepIdx &ix, const Twist &tw) const {
+        const real *Mm = sM + (long)i * MSZ;
         G4_UNROLL
-        for (int k = 0; k + 1 < NX; ++k) o.mr[k] = X::lds_ld(Mm, mo.R[k]);
+        for (int k = 0; k + 1 < NX; ++k) o.mr[k] = X::lds_ld(Mm, ix.R[k]);
         G4_UNROLL
-        for (int k = 1; k < NX; ++k) o.mc[k - 1] = X::lds_ld(Mm, mo.C[k]);
-        o.di = X::lds_ld(Mm, rc + NXL);
-        o.px = X::lds_ld(sPx, rc + m * NX);
-        o.v = X::lds_ld(sV, rc + m * NX);
+        for (int k = 1; k < NX; ++k) o.mc[k - 1] = X::lds_ld(Mm, ix.C[k]);
+        o.di = X::lds_ld(Mm, ix.D);
+        const int mb_ = T - 1 + tw.dl - i;
+        o.vi = X::seli(bottom(), X::splati((mb_ < T ? mb_ : T - 1) * NX), X::splati(i * NX)) + rc;
+        const V px = X::lds_ld(sPx, o.vi);
+        o.pa = X::sel(bottom(), X::splat(real(1)), px);   // P_x where the top chain scales, 1 where the bottom chain does
+        o.pb = X::sel(bottom(), px, X::splat(real(1)));   // and the other way round
+        o.v = X::lds_ld(sV, o.vi);
     }
-    G4_FN void load_fwd(int m, SweepOps &o, const MOff &mo) const {   // rows of A_{m-1} (lane r: row r)
-        if (m > 0) {
-            const VI base = rc * N + (m - 1) * FSZ;
-            G4_UNROLL
-            for (int k = 0; k < NX; ++k) o.a[k] = X::lds_ld(sF, base + k);
-        }
-        load_factor(m, o, mo);
-    }
-    G4_FN void load_bwd(int m, SweepOps &o, const MOff &mo) const {   // columns of A_m (lane k: column k)
-        const VI cb = rc + m * FSZ;
+    G4_FN void load_step(int i, SweepOps &o, const SweepIdx &ix, const Twist &tw) const {
+        const real *Fi = sF + (long)i * FSZ;
         G4_UNROLL
-        for (int q2 = 0; q2 < NX; ++q2) o.a[q2] = X::lds_ld(sF, cb + q2 * N);
-        load_factor(m, o, mo);
+        for (int k = 0; k < NX; ++k) o.a[k] = X::lds_ld(Fi, ix.A[k]);
+        load_factor(i, o, ix, tw);
     }
-    // S~_m^-1 v = M' (D^-1 (M v)) with the stage's packed factor block in o
+    // the middle block: both halves read the ONE factor block at slot mid; their A operands and scalings differ as usual
+    G4_FN void load_mid(SweepOps &o, const SweepIdx &ix, const Twist &tw) const {
+        const real *Fi = sF + (long)tw.steps * FSZ;
+        G4_UNROLL
+        for (int k = 0; k < NX; ++k) o.a[k] = X::lds_ld(Fi, ix.A[k]);
+        const real *Mm = sM + (long)tw.mid * MSZ;
+        const VI hb = X::seli(bottom(), X::splati(tw.MB0 * MSZ), X::splati(0));
+        G4_UNROLL
+        for (int k = 0; k + 1 < NX; ++k) o.mr[k] = X::lds_ld(Mm, ix.R[k] - hb);
+        G4_UNROLL
+        for (int k = 1; k < NX; ++k) o.mc[k - 1] = X::lds_ld(Mm, ix.C[k] - hb);
+        o.di = X::lds_ld(Mm, ix.D - hb);
+        o.vi = rc + tw.mid * NX;
+        const V px = X::lds_ld(sPx, o.vi);
+        o.pa = X::sel(bottom(), X::splat(real(1)), px);
+        o.pb = X::sel(bottom(), px, X::splat(real(1)));
+        o.v = X::lds_ld(sV, o.vi);
+    }
+    // S~_m^-1 v = M' (D^-1 (M v)) with the block's packed factor in o
     G4_FN V Sinv(const V &v, const SweepOps &o) const {
         if constexpr (NX == 1) {
             return v * o.di;
@@ -495,44 +583,63 @@ struct Solver {
         for (int i = 0; i < SL; ++i) X::lds_st(sV, tof(i) * NX + r, Fp[i] - prx[i] - bb.ys[i], mx(i));
         X::fence();
         tick(4);
-        // forward sweep
-        MOff mo;
-        m_offsets(mo);
-        // (both sweeps are unrolled four stages deep: the stage offsets of the LDS reads become immediates instead of
-        //  one address addition per matrix entry, and the two operand sets alternate by a compile-time index)
+        // inwards: step i takes block i on the top chain and block T-1+dl-i on the bottom chain. (Both loops are unrolled
+        // four steps deep: the step offsets of the LDS reads become immediates, and the two operand sets alternate by a
+        // compile-time index.)
+        const Twist tw = twist();
+        const VM bot = bottom();
+        const VM st_ok = ((lane & 16) == 0) & mXr();
+        const VI other = (lane + 32) & 63;
+        SweepIdx ix;
+        m_offsets(ix, tw);
+        a_offsets_in(ix, tw);
         SweepOps so[2];
-        load_fwd(0, so[0], mo);
-        V q = zero(), p = zero();
-        for (int m0 = 0; m0 < T; m0 += 4) {
+        load_factor(0, so[0], ix, tw);
+        if (tw.steps > 1) load_step(1, so[1], ix, tw);
+        V p = Sinv(so[0].v, so[0]);       // step 0: nothing precedes either chain's first block
+        X::lds_st(sV, so[0].vi, p, st_ok & (!bot | um(tw.dl == 0)));
+        V q = keep(!bot | um(tw.dl == 0), p * so[0].pa);
+        for (int i0 = 1; i0 < tw.steps; i0 += 4) {
             G4_UNROLL
-            for (int mm = 0; mm < 4; ++mm) {
-                const int m = m0 + mm;
-                if (m >= T) break;
-                const SweepOps &c = so[mm & 1];
-                if (m + 1 < T) load_fwd(m + 1, so[(mm + 1) & 1], mo);
-                V v = c.v;
-                if (m > 0) fmac_row<X, 0, NX>(v, q, c.a);
-                p = Sinv(v, c);
-                X::lds_st(sV, r + m * NX, p, g0() & mXr());
-                q = p * c.px;
+            for (int ii = 0; ii < 4; ++ii) {
+                const int i = i0 + ii;
+                if (i >= tw.steps) break;
+                const SweepOps &c = so[(ii + 1) & 1];
+                if (i + 1 < tw.steps) load_step(i + 1, so[ii & 1], ix, tw);
+                V acc = zero();
+                fmac_row<X, 0, NX>(acc, q, c.a);
+                p = Sinv(c.v + c.pb * acc, c);
+                X::lds_st(sV, c.vi, p, st_ok);
+                q = p * c.pa;
             }
         }
+        {   // the middle block takes both chains' corrections; its solution starts both outward chains
+            SweepOps &c = so[0];
+            load_mid(c, ix, tw);
+            V acc = zero();
+            fmac_row<X, 0, NX>(acc, q, c.a);
+            V t = c.pb * acc;
+            t = t + X::gather(t, other);
+            p = Sinv(c.v + t, c);
+            X::lds_st(sV, c.vi, p, st_ok & !bot);
+            q = p * c.pb;
+        }
         tick(5);
-        // backward sweep
-        load_bwd(T - 2, so[0], mo);
-        V xn = p;
-        for (int m0 = T - 2; m0 >= 0; m0 -= 4) {
+        // outwards from the middle: y = p + S~^-1 (coupling to the block solved before)
+        a_offsets_out(ix, tw);
+        load_step(tw.steps - 1, so[0], ix, tw);
+        for (int i0 = tw.steps - 1; i0 >= 0; i0 -= 4) {
             G4_UNROLL
-            for (int mm = 0; mm < 4; ++mm) {
-                const int m = m0 - mm;
-                if (m < 0) break;
-                const SweepOps &c = so[mm & 1];
-                if (m > 0) load_bwd(m - 1, so[(mm + 1) & 1], mo);
-                V wq = zero();
-                fmac_row<X, 0, NX>(wq, xn, c.a);
-                wq = wq * c.px;
-                xn = c.v + Sinv(wq, c);
-                X::lds_st(sV, r + m * NX, xn, g0() & mXr());
+            for (int ii = 0; ii < 4; ++ii) {
+                const int i = i0 - ii;
+                if (i < 0) break;
+                const SweepOps &c = so[ii & 1];
+                if (i > 0) load_step(i - 1, so[(ii + 1) & 1], ix, tw);
+                V acc = zero();
+                fmac_row<X, 0, NX>(acc, q, c.a);
+                const V y = c.v + Sinv(c.pa * acc, c);
+                X::lds_st(sV, c.vi, y, st_ok & (!bot | um(i >= tw.dl)));
+                q = y * c.pb;
             }
         }
         X::fence();

@@ -64,6 +64,7 @@ struct EmuX {
     static V absv(const V &a) { V o; for (int l = 0; l < W; ++l) o.v[l] = std::fabs(a.v[l]); return o; }
     static real first(const V &a) { return a.v[0]; }
     static int firsti(const VI &a) { return a.v[0]; }
+    static int lanei(const VI &a, int l) { return a.v[l]; }
     static V rcp(const V &a) { V o; for (int l = 0; l < W; ++l) o.v[l] = real(1) / a.v[l]; return o; }
     // row_newbcast: lane K of each 16-lane row
     template <int K> static V bcast(const V &x) { V o; for (int l = 0; l < W; ++l) o.v[l] = x.v[(l & 48) + K]; return o; }

@@ -68,3 +68,32 @@ def test_resident_backward_kernel_emulated_vs_oracle(name):
     b = emu.backward("f64", _bm(g["Cd"]), _bm(g["F"]), g["qp_lams"][0], g["qp_slacks"][0], gbar)
     for u, v in zip(a, b):
         assert np.abs(u - v).max() < 1e-8 * max(1.0, np.abs(u).max())
+
+
+@pytest.mark.parametrize("T", [2, 3, 4, 5, 6, 9, 12, 19, 20])
+@pytest.mark.parametrize("dims", [(13, 4), (4, 2), (14, 4), (2, 1)])
+def test_resident_kernel_emulated_every_horizon(T, dims):
+    """The two elimination chains of the twisted factorisation have equal length for odd T and differ by one block for
+    even T (the bottom chain then starts one step late), and the smallest horizons have an empty bottom chain (T = 2)
+    or single-block chains (T = 3): every case against the C oracle's one-directional structured solver, forward
+    (two instances, one with active bounds) and backward."""
+    import torch
+    from deq_mpc_corl_amd import synthetic_problem
+    from oracle import ipm_py
+    from tests.emu import ipm_g4_emu_py as emu
+    nx, nu = dims
+    if T in (5, 6, 9, 12, 19) and dims != (13, 4):
+        pytest.skip("the intermediate horizons run on the flagship size only (emulator time)")
+    p = synthetic_problem(2, T, nx, nu, seed=T, dtype=torch.float64, device="cpu")
+    c = lambda a: a.numpy()
+    args = (c(p.Qd), c(p.q), c(p.F), c(p.c), c(p.x0), c(p.u_hi) * 0.2, c(p.u_lo) * 0.2)
+    got = emu.forward("f64", *args, exit_mode="fixed")
+    orc = ipm_py.forward("f64", *args, solver=0, exit_mode=1)
+    assert int(got["info"].max()) == 0
+    for k in ("zhat", "nus", "lams", "slacks"):
+        assert np.abs(got[k] - orc[k]).max() < 1e-9 * max(1.0, np.abs(orc[k]).max()), k
+    gbar = np.random.default_rng(T).standard_normal(orc["zhat"].shape)
+    a = ipm_py.backward("f64", args[0], args[2], orc["lams"], orc["slacks"], gbar, solver=0)
+    b = emu.backward("f64", args[0], args[2], orc["lams"], orc["slacks"], gbar)
+    for u, v in zip(a, b):
+        assert np.abs(u - v).max() < 1e-8 * max(1.0, np.abs(u).max())
