@@ -37,21 +37,31 @@ constexpr int kSlots = 5;   // stage slots per lane group: T <= 4 * kSlots
 #endif
 template <typename real> constexpr int kWavesPerSimd = sizeof(real) == 4 ? ALQP_G4_F32_WAVES : 1;
 
+// The kernels use no static LDS, so the dynamic allocation of a launch starts at LDS address 0. Handing the solver
+// an address inside it as a LITERAL lets every LDS access fold into (lane offset register) + (immediate): the address
+// of an `extern __shared__` symbol is only resolved after instruction selection and leaves one `v_add_u32 v, 0, v` in
+// front of each of the ~170 LDS instructions that combine a lane offset with a block offset (40 per sweep step).
+// The literal is kLdsBase, not 0: a pointer made from the constant 0 is a null pointer to the compiler, whatever the
+// address space. Solver::lds_words() ends in 16 spare words, which cover the shift.
+constexpr unsigned long kLdsBase = 16;
+template <typename real>
+__device__ __forceinline__ real *lds_base() {
+    return (real *)reinterpret_cast<__attribute__((address_space(3))) real *>(kLdsBase);
+}
+
 template <typename real, int NX, int NU>
 __global__ __launch_bounds__(64, kWavesPerSimd<real>) void k_ipm_g4(const IpmArgs<real> a) {
-    extern __shared__ __align__(16) unsigned char lds_raw[];
     const int b = blockIdx.x;
     if (b >= a.B) return;
-    Solver<real, NX, NU, kSlots, GpuX<real>> S(a, reinterpret_cast<real *>(lds_raw), b);
+    Solver<real, NX, NU, kSlots, GpuX<real>> S(a, lds_base<real>(), b);
     S.run_forward();
 }
 
 template <typename real, int NX, int NU>
 __global__ __launch_bounds__(64, kWavesPerSimd<real>) void k_ipm_g4_backward(const IpmArgs<real> a, const real *lams, const real *slacks) {
-    extern __shared__ __align__(16) unsigned char lds_raw[];
     const int b = blockIdx.x;
     if (b >= a.B) return;
-    Solver<real, NX, NU, kSlots, GpuX<real>> S(a, reinterpret_cast<real *>(lds_raw), b);
+    Solver<real, NX, NU, kSlots, GpuX<real>> S(a, lds_base<real>(), b);
     S.run_backward(lams, slacks);
 }
 

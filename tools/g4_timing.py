@@ -8,8 +8,8 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-NAMES = ["problem load", "residuals", "factor: Dt, Pu", "factor: blocks", "apply: right-hand side", "forward sweep",
-         "backward sweep", "apply: outputs", "K product", "step lengths, updates", "workspace, outputs",
+NAMES = ["problem load", "residuals", "factor: Dt, Pu", "factor: blocks", "apply: right-hand side", "inward sweep",
+         "outward sweep", "apply: outputs", "K product", "step lengths, updates", "workspace, outputs",
          "block: loads + F P F'", "block: Z", "block: Z D^-1 Z'", "block: L D L'", "block: inverse + store"]
 
 
