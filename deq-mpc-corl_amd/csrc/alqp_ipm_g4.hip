@@ -42,11 +42,10 @@ template <typename real> constexpr int kWavesPerSimd = sizeof(real) == 4 ? ALQP_
 // of an `extern __shared__` symbol is only resolved after instruction selection and leaves one `v_add_u32 v, 0, v` in
 // front of each of the ~170 LDS instructions that combine a lane offset with a block offset (40 per sweep step).
 // The literal is kLdsBase, not 0: a pointer made from the constant 0 is a null pointer to the compiler, whatever the
-// address space. Solver::lds_words() ends in 16 spare words, which cover the shift.
-constexpr unsigned long kLdsBase = 16;
+// address space. Solver::lds_words() counts the two words of the shift.
 template <typename real>
 __device__ __forceinline__ real *lds_base() {
-    return (real *)reinterpret_cast<__attribute__((address_space(3))) real *>(kLdsBase);
+    return (real *)reinterpret_cast<__attribute__((address_space(3))) real *>(2 * sizeof(real));
 }
 
 template <typename real, int NX, int NU>

@@ -70,6 +70,18 @@ template <class X, int K0, int CNT, class V>
 G4_FN void fmac_multi(V *acc, const V &x, const V &m) { if constexpr (CNT > 0) X::template multi<K0, CNT>(acc, x, m); }
 template <class X, int K, int CNT, class V>
 G4_FN void fmac_vec(V &acc, const V *x, const V *m) { if constexpr (CNT > 0) X::template vec<K, CNT>(acc, x, m); }
+//   X::rank<NA, NT>(acc, x, m)    acc[i] += bcast_i(x[k]) * m[k], i < NA, k < NT   NT rank-1 updates of a row set, ONE block
+// N rank-1 updates in blocks of as many terms as one block takes (X::rank_max)
+template <class X, int NA, int N, class V>
+G4_FN void fmac_rank(V *acc, const V *x, const V *m) {
+    constexpr int B = X::rank_max(NA);
+    if constexpr (N > B) {
+        X::template rank<NA, B>(acc, x, m);
+        fmac_rank<X, NA, N - B>(acc, x + B, m + B);
+    } else if constexpr (N > 0) {
+        X::template rank<NA, N>(acc, x, m);
+    }
+}
 
 template <typename real, int NX, int NU, int SL, class X>
 struct Solver {
@@ -87,7 +99,7 @@ struct Solver {
     struct KV { V xs[SL], ys[SL], c0[SL], c1[SL]; };   // a KKT vector (x | s | z | y) in registers
 
     static ALQP_HD long lds_words(int T) {
-        return (long)(T - 1) * FSZ + (long)T * MSZ + 2L * T * NX + 4L * T + 16;
+        return (long)(T - 1) * FSZ + (long)T * MSZ + 2L * T * NX + 4L * T + NX + 2;   // + NX zero words + the base shift (.hip)
     }
 
     const IpmArgs<real> &a;
@@ -95,7 +107,7 @@ struct Solver {
     const int b, T;
     const real e;
     real *w;                             // this instance's workspace slab
-    real *sF, *sM, *sV, *sPx, *sPu;      // LDS
+    real *sF, *sM, *sV, *sPx, *sPu, *sZ; // LDS (sZ: NX words that hold 0)
     const real *Cdg, *cg, *Fg, *fg, *x0g;
     VI lane, r, g, qd, j, rc;            // lane-derived indices: recomputed by refresh() at the start of every phase
     V hq;                                // h on the bound rows (quarter 0: u_hi, quarter 1: -u_lo)
@@ -117,7 +129,8 @@ struct Solver {
         sM = p; p += (long)T * MSZ;
         sV = p; p += (long)T * NX;
         sPx = p; p += (long)T * NX;
-        sPu = p;
+        sPu = p; p += 4L * T;
+        sZ = p;
         Cdg = a.Cd + (long)b * a.sC_b;
         cg = a.c ? a.c + (long)b * a.sC_b : nullptr;
         Fg = a.F + (long)b * a.sF_b;
@@ -232,6 +245,7 @@ struct Solver {
         hq = zero();
         if (a.uhi && a.ulo) hq = X::g_ld(a.uhi, j, mQ() & (qd == 0)) - X::g_ld(a.ulo, j, mQ() & (qd == 1));
         X::lds_st(sM, lane * MSZ + ZC, zero(), lane < T);   // the zero cell of every factor slot
+        X::lds_st(sZ, lane, zero(), lane < NX);
         X::fence();
         tick(0);
     }
@@ -391,23 +405,26 @@ struct Solver {
             const VM live = !bot | um(i >= tw.dl);
             const VM base = !bot | um(!is_mid);                               // who adds P_x + eps + F P F'
             const V pxo = X::lds_ld(sPx, X::seli(bot, X::splati((mb_ < T ? mb_ : T - 1) * NX), X::splati(i * NX)) + rc);
+            const V dg = pxo + e;      // lane r: the P_x + eps part of S[r][r]; joins the pivot when column r is eliminated (ldl)
             V S[NX];
             G4_UNROLL
-            for (int c = 0; c < NX; ++c) S[c] = keep((r == c) & base, pxo + e);
+            for (int c = 0; c < NX; ++c) S[c] = zero();
             // rows of F_{m-1} (none for block 0), scaled by P_{m-1}
             const int st = i > 0 ? i - 1 : 0;
             const int sbt = tw.mid - tw.dl + i < T - 2 ? tw.mid - tw.dl + i : T - 2;
             const VI fb = X::seli(bot, X::splati(sbt * FSZ), X::splati(st * FSZ)) + rc * N;
             const VI pblk = X::seli(bot, X::splati(mb_ - 1), X::splati(st));
             const VM f_ok = base & live & (mv > 0);
+            // lanes without an F term read their P from the zero words behind sPu: fp = 0 there (F itself is finite data)
+            const VI pxb = X::seli(f_ok, pblk * NX, X::splati((int)(sZ - sPx)));
+            const VI pub = X::seli(f_ok, pblk * 4, X::splati((int)(sZ - sPu)));
             V fr[N], fp[N];
             G4_UNROLL
             for (int k = 0; k < N; ++k) {
-                fr[k] = keep(f_ok, X::lds_ld(sF, fb + k));
-                fp[k] = fr[k] * (k < NX ? X::lds_ld(sPx, pblk * NX + k) : X::lds_ld(sPu, pblk * 4 + (k - NX)));
+                fr[k] = X::lds_ld(sF, fb + k);
+                fp[k] = fr[k] * (k < NX ? X::lds_ld(sPx, pxb + k) : X::lds_ld(sPu, pub + (k - NX)));
             }
-            G4_UNROLL
-            for (int k = 0; k < N; ++k) fmac_multi<X, 0, NX>(S, fr[k], fp[k]);   // F P F'
+            fmac_rank<X, NX, N>(S, fr, fp);   // F P F'
             tick(11);
             // coupling rows: top fp[c] = A_{m-1}[r][c] P_{m-1}[c]; bottom P_m[r] A_m[c][r] (column r of A_m; none for block T-1)
             int zs = tw.mid + i - tw.dl - 1;
@@ -420,21 +437,18 @@ struct Solver {
                 zsrc[c] = X::sel(bot, keep(zb_ok, X::lds_ld(sF, zb + c * N) * pxo), fp[c]);
                 Z[c] = zsrc[c];
             }
-            z_rows<0>(Z, Mrow, zsrc);   // Z[r][c] = -(zsrc[c] + sum_{k<c} M[c][k] zsrc[k]), M[c][k] = lane c's Mrow[k]
+            if constexpr (NX > 1) X::template ztri<NX>(Z, Mrow, zsrc);   // Z[r][c] = -(zsrc[c] + sum_{k<c} M[c][k] zsrc[k]), M[c][k] = lane c's Mrow[k]
             G4_UNROLL
             for (int c = 0; c < NX; ++c) { zd[c] = Z[c] * dprev[c]; Z[c] = -Z[c]; }
             tick(12);
-            G4_UNROLL
-            for (int k = 0; k < NX; ++k) fmac_multi<X, 0, NX>(S, Z[k], zd[k]);   // S -= Z D^-1 Z'
+            fmac_rank<X, NX, NX>(S, Z, zd);   // S -= Z D^-1 Z'
             tick(13);
             if (is_mid) {
                 const VI other = (lane + 32) & 63;
                 G4_UNROLL
                 for (int c = 0; c < NX; ++c) S[c] = S[c] + X::gather(S[c], other);
             }
-            G4_UNROLL
-            for (int k = 0; k < NX; ++k) Mrow[k] = keep(r == k, X::splat(real(1)));
-            ldl<0>(S, Mrow, dprev, mv, live);
+            ldl<0>(S, Mrow, dprev, dg, mv, live);
             if (i < tw.dl) {   // the bottom chain has not started: it has no previous block
                 G4_UNROLL
                 for (int k = 0; k < NX; ++k) { Mrow[k] = keep(!bot, Mrow[k]); dprev[k] = keep(!bot, dprev[k]); }
@@ -444,7 +458,9 @@ struct Solver {
             const VM st_ok = ((lane & 16) == 0) & mXr() & live & (!bot | um(!is_mid));
             G4_UNROLL
             for (int k = 0; k + 1 < NX; ++k) X::lds_st(sM, mo + (((rc * (rc - 1)) >> 1) + k), Mrow[k], st_ok & (r > k));
-            X::lds_st(sM, mo + (r + NXL), dlane(dprev), st_ok);
+            const VM d_ok = ((lane & 31) == 0) & live & (!bot | um(!is_mid));   // 1/d_k is uniform inside a half: one lane stores all
+            G4_UNROLL
+            for (int k = 0; k < NX; ++k) X::lds_st(sM, mo + (NXL + k), dprev[k], d_ok);
             X::fence();
             tick(15);
         }
@@ -452,35 +468,21 @@ struct Solver {
         info = it ? it : ib;
         tick(3);
     }
-    // Z[c] += sum_{k<c} bcast_c(Mrow[k]) * src[k], as rank-1 updates over k (entries with c <= k are zero and skipped)
-    template <int K>
-    G4_FN void z_rows(V *Z, const V *Mrow, const V *fp) const {
-        if constexpr (K + 1 < NX) {
-            fmac_multi<X, K + 1, NX - 1 - K>(Z + K + 1, Mrow[K], fp[K]);
-            z_rows<K + 1>(Z, Mrow, fp);
-        }
-    }
-    // lane k's element k of a uniform array (for the store of 1/d)
-    G4_FN V dlane(const V *d) const {
-        V o = zero();
-        G4_UNROLL
-        for (int k = 0; k < NX; ++k) o = X::sel(r == k, d[k], o);
-        return o;
-    }
-    // column C of S~ = L D L': d = S[C][C] (uniform; a non-positive pivot is replaced by |d| and flagged),
-    // L[r][C] = S[r][C] / d for r > C; the row operation row_r -= L[r][C] row_C on the trailing columns of S and on the
-    // leading columns of the identity that becomes M = L^-1
+    // column C of S~ = L D L': d = S[C][C] + its P_x + eps part (uniform; a non-positive pivot is replaced by |d| and
+    // flagged), L[r][C] = S[r][C] / d for r > C; the row operation row_r -= L[r][C] row_C on the trailing columns of S
+    // and on the leading columns of the identity that becomes M = L^-1 (X::pivot, one block). Column C of M below the
+    // diagonal is -L[:, C] at this point; M's unit diagonal is never read (nor stored) and is not formed.
     template <int C>
-    G4_FN void ldl(V *S, V *Mrow, V *dinv, const VI &mv, const VM &live) {
+    G4_FN void ldl(V *S, V *Mrow, V *dinv, const V &dg, const VI &mv, const VM &live) {
         if constexpr (C < NX) {
-            const V d = X::template bcast<C>(S[C]);
+            const V d = X::template bcast<C>(S[C] + dg);
             infov = X::seli((infov == 0) & live & !(d > zero()), mv * NX + (C + 1), infov);
             const V di = X::rcp(X::absv(d));
             dinv[C] = di;
             const V nl = keep(r > C, -(S[C] * di));
-            fmac_multi<X, C + 1, NX - 1 - C>(S + C + 1, S[C], nl);   // S[r][k] -= L[r][C] * S[k][C], k > C
-            if constexpr (C + 1 < NX) X::template self<C, C + 1>(Mrow, nl);   // M[r][k] -= L[r][C] * M[C][k], k <= C
-            ldl<C + 1>(S, Mrow, dinv, mv, live);
+            Mrow[C] = nl;
+            if constexpr (NX > 1) X::template pivot<C, NX>(S, Mrow, nl);
+            ldl<C + 1>(S, Mrow, dinv, dg, mv, live);
         }
     }
 

@@ -90,6 +90,25 @@ struct EmuX {
             for (int l = 0; l < W; ++l) acc[i].v[l] = std::fma(old.v[(l & 48) + K], ms.v[l], old.v[l]);
         }
     }
+    // the whole-matrix blocks of the GPU policy (one asm statement each there), in their order of operations
+    static constexpr int rank_max(int na) { return (30 - na) / 2 < 8 ? (30 - na) / 2 : 8; }
+    template <int NA, int NT> static void rank(V *acc, const V *x, const V *m) {
+        for (int k = 0; k < NT; ++k) multi<0, NA>(acc, x[k], m[k]);
+    }
+    template <int C, int NXX> static void pivot(V *S, V *M, const V &nl) {
+        const V xs = S[C], ms = nl;
+        for (int i = C + 1; i < NXX; ++i)
+            for (int l = 0; l < W; ++l) S[i].v[l] = std::fma(xs.v[(l & 48) + i], ms.v[l], S[i].v[l]);
+        for (int i = 0; i < C; ++i) {
+            const V old = M[i];
+            for (int l = 0; l < W; ++l) M[i].v[l] = std::fma(old.v[(l & 48) + C], ms.v[l], old.v[l]);
+        }
+    }
+    template <int NXX> static void ztri(V *Z, const V *M, const V *s) {
+        for (int k = 0; k + 1 < NXX; ++k)
+            for (int c = k + 1; c < NXX; ++c)
+                for (int l = 0; l < W; ++l) Z[c].v[l] = std::fma(M[k].v[(l & 48) + c], s[k].v[l], Z[c].v[l]);
+    }
     template <int K, int C> static void vec(V &acc, const V *x, const V *m) {
         if constexpr (C > 13) { vec<K, 13>(acc, x, m); vec<K, C - 13>(acc, x + 13, m + 13); }
         else {

@@ -74,6 +74,61 @@ def vec(n, t):
     return f"    template <int K> static G4_FN void vec_{n}({t} &acc, const {t} *x, const {t} *m) {{\n{body}    }}\n"
 
 
+NXS = (2, 4, 6, 8, 10, 12, 13, 14)   # state sizes of csrc/alqp_dims.hpp: the whole-matrix blocks below exist for these
+
+
+def rank(na, nt, t):
+    """acc[i] += bcast_i(x[k]) * m[k], i < na, for k < nt in turn: nt rank-1 updates of an na-column row set in ONE
+    block (one hazard pad instead of nt; na + 2 nt operands <= 30)."""
+    lines = ['"s_nop 1\\n\\t"']
+    for k in range(nt):
+        for i in range(na):
+            lines.append(f'"v_fmac_{SFX[t]}_dpp %{i}, %{na + k}, %{na + nt + k} row_newbcast:{i}{TAIL}"')
+    outs = ", ".join(f'"+&v"(acc[{i}])' for i in range(na))
+    ins = ", ".join([f'"v"(x[{k}])' for k in range(nt)] + [f'"v"(m[{k}])' for k in range(nt)])
+    return (f"    static G4_FN void rank_{na}_{nt}({t} *acc, const {t} *x, const {t} *m) {{\n"
+            "        asm(" + "\n            ".join(lines) + f"\n            : {outs} : {ins});\n    }}\n")
+
+
+def pivot(nx, c, t):
+    """One elimination step of the L D L' / M = L^-1 pivot loop as ONE block: the trailing columns of S
+    (S[k] += bcast_k(S[c]) * nl, k > c) and the leading columns of M (M[i] += bcast_c(M[i]) * nl, i < c)."""
+    n1, n2 = nx - 1 - c, c
+    if n1 + n2 == 0:
+        return ""
+    lines = ['"s_nop 1\\n\\t"']
+    xo, mo = n1 + n2, n1 + n2 + 1
+    for i in range(n1):
+        lines.append(f'"v_fmac_{SFX[t]}_dpp %{i}, %{xo}, %{mo} row_newbcast:{c + 1 + i}{TAIL}"')
+    for i in range(n2):
+        lines.append(f'"v_fmac_{SFX[t]}_dpp %{n1 + i}, %{n1 + i}, %{mo} row_newbcast:{c}{TAIL}"')
+    outs = ", ".join([f'"+&v"(S[{c + 1 + i}])' for i in range(n1)] + [f'"+&v"(M[{i}])' for i in range(n2)])
+    return (f"    static G4_FN void pivot_{nx}_{c}({t} *S, {t} *M, const {t} &nl) {{\n"
+            "        asm(" + "\n            ".join(lines) + f"\n            : {outs} : \"v\"(S[{c}]), \"v\"(nl));\n    }}\n")
+
+
+def ztri(nx, k0, k1, t):
+    """Z[c] += bcast_c(M[k]) * s[k] for k0 <= k < k1, c > k: the strictly-lower part of Z = S M' in two blocks."""
+    lo = k0 + 1                       # accumulators Z[lo .. nx)
+    na, nk = nx - lo, k1 - k0
+    lines = ['"s_nop 1\\n\\t"']
+    for k in range(k0, k1):
+        for c in range(k + 1, nx):
+            lines.append(f'"v_fmac_{SFX[t]}_dpp %{c - lo}, %{na + k - k0}, %{na + nk + k - k0} row_newbcast:{c}{TAIL}"')
+    outs = ", ".join(f'"+&v"(Z[{c}])' for c in range(lo, nx))
+    ins = ", ".join([f'"v"(M[{k}])' for k in range(k0, k1)] + [f'"v"(s[{k}])' for k in range(k0, k1)])
+    return (f"    static G4_FN void ztri_{nx}_{k0}({t} *Z, const {t} *M, const {t} *s) {{\n"
+            "        asm(" + "\n            ".join(lines) + f"\n            : {outs} : {ins});\n    }}\n")
+
+
+def ztri_split(nx):
+    """[0, h) and [h, nx-1): both blocks within 30 operands."""
+    h = (nx - 1 + 1) // 2
+    while (nx - 1) + 2 * h > 30:
+        h -= 1
+    return h
+
+
 def dispatcher(name, sig, call, maxn, split=None):
     s = f"    template <int K0, int CNT> static G4_FN void {name}({sig}) {{\n"
     for n in range(1, maxn + 1):
@@ -233,6 +288,42 @@ def main():
             body += multi(n, t) + selfu(n, t)
         for n in range(1, 14):   # 2 accumulators + 2 n inputs + K: the 30-operand limit of an asm statement
             body += vec(n, t)
+        for nx in NXS:
+            for nt in range(1, min(8, (30 - nx) // 2) + 1):
+                body += rank(nx, nt, t)
+            for c in range(nx):
+                body += pivot(nx, c, t)
+            if nx > 1:
+                h = ztri_split(nx)
+                body += ztri(nx, 0, h, t)
+                if h < nx - 1:
+                    body += ztri(nx, h, nx - 1, t)
+    body += "    // whole-matrix blocks (state sizes of alqp_dims.hpp)\n"
+    body += "    template <int NA, int NT> static G4_FN void rank(real *acc, const real *x, const real *m) {\n"
+    first = True
+    for nx in NXS:
+        for nt in range(1, min(8, (30 - nx) // 2) + 1):
+            body += f"        {'if' if first else 'else if'} constexpr (NA == {nx} && NT == {nt}) rank_{nx}_{nt}(acc, x, m);\n"
+            first = False
+    body += "        else static_assert(NA < 0, \"rank: no block of this shape\");\n    }\n"
+    body += "    static constexpr int rank_max(int na) { return (30 - na) / 2 < 8 ? (30 - na) / 2 : 8; }   // terms per block\n"
+    body += "    template <int C, int NXX> static G4_FN void pivot(real *S, real *M, const real &nl) {\n"
+    first = True
+    for nx in NXS:
+        for c in range(nx):
+            if nx - 1 - c + c == 0:
+                continue
+            body += f"        {'if' if first else 'else if'} constexpr (NXX == {nx} && C == {c}) pivot_{nx}_{c}(S, M, nl);\n"
+            first = False
+    body += "        else static_assert(NXX < 0, \"pivot: no block of this shape\");\n    }\n"
+    body += "    template <int NXX> static G4_FN void ztri(real *Z, const real *M, const real *s) {\n"
+    first = True
+    for nx in NXS:
+        h = ztri_split(nx)
+        calls = f"ztri_{nx}_0(Z, M, s);" + (f" ztri_{nx}_{h}(Z, M, s);" if h < nx - 1 else "")
+        body += f"        {'if' if first else 'else if'} constexpr (NXX == {nx}) {{ {calls} }}\n"
+        first = False
+    body += "        else static_assert(NXX < 0, \"ztri: no block of this shape\");\n    }\n"
     body += "    // chain-length dispatch (CNT = 0: nothing)\n"
     body += dispatcher("row", "real &acc, const real &x, const real *m", "acc, x, m", MAXN)
     body += dispatcher("multi", "real *acc, const real &x, const real &m", "acc, x, m", 16)
