@@ -99,7 +99,7 @@ struct Solver {
     struct KV { V xs[SL], ys[SL], c0[SL], c1[SL]; };   // a KKT vector (x | s | z | y) in registers
 
     static ALQP_HD long lds_words(int T) {
-        return (long)(T - 1) * FSZ + (long)T * MSZ + 2L * T * NX + 4L * T + NX + 2;   // + NX zero words + the base shift (.hip)
+        return (long)(T - 1) * FSZ + (long)T * MSZ + 2L * T * NX + 4L * T + NX + 3;   // + NX zero words, a 1, the base shift (.hip)
     }
 
     const IpmArgs<real> &a;
@@ -107,7 +107,7 @@ struct Solver {
     const int b, T;
     const real e;
     real *w;                             // this instance's workspace slab
-    real *sF, *sM, *sV, *sPx, *sPu, *sZ; // LDS (sZ: NX words that hold 0)
+    real *sF, *sM, *sV, *sPx, *sPu, *sZ; // LDS (sZ: NX words that hold 0, then one that holds 1)
     const real *Cdg, *cg, *Fg, *fg, *x0g;
     VI lane, r, g, qd, j, rc;            // lane-derived indices: recomputed by refresh() at the start of every phase
     V hq;                                // h on the bound rows (quarter 0: u_hi, quarter 1: -u_lo)
@@ -245,7 +245,7 @@ struct Solver {
         hq = zero();
         if (a.uhi && a.ulo) hq = X::g_ld(a.uhi, j, mQ() & (qd == 0)) - X::g_ld(a.ulo, j, mQ() & (qd == 1));
         X::lds_st(sM, lane * MSZ + ZC, zero(), lane < T);   // the zero cell of every factor slot
-        X::lds_st(sZ, lane, zero(), lane < NX);
+        X::lds_st(sZ, lane, X::sel(lane < NX, zero(), X::splat(real(1))), lane < NX + 1);
         X::fence();
         tick(0);
     }
@@ -524,9 +524,11 @@ struct Solver {
         o.di = X::lds_ld(Mm, ix.D);
         const int mb_ = T - 1 + tw.dl - i;
         o.vi = X::seli(bottom(), X::splati((mb_ < T ? mb_ : T - 1) * NX), X::splati(i * NX)) + rc;
-        const V px = X::lds_ld(sPx, o.vi);
-        o.pa = X::sel(bottom(), X::splat(real(1)), px);   // P_x where the top chain scales, 1 where the bottom chain does
-        o.pb = X::sel(bottom(), px, X::splat(real(1)));   // and the other way round
+        // pa = P_x where the top chain scales and 1 where the bottom chain does, pb the other way round: selected by
+        // ADDRESS (the 1 is the word behind the zero words) - a select on the loaded value would wait for the whole batch
+        const VI one = X::splati((int)(sZ + NX - sPx));
+        o.pa = X::lds_ld(sPx, X::seli(bottom(), one, o.vi));
+        o.pb = X::lds_ld(sPx, X::seli(bottom(), o.vi, one));
         o.v = X::lds_ld(sV, o.vi);
     }
     G4_FN void load_step(int i, SweepOps &o, const SweepIdx &ix, const Twist &tw) const {
@@ -548,9 +550,9 @@ struct Solver {
         for (int k = 1; k < NX; ++k) o.mc[k - 1] = X::lds_ld(Mm, ix.C[k] - hb);
         o.di = X::lds_ld(Mm, ix.D - hb);
         o.vi = rc + tw.mid * NX;
-        const V px = X::lds_ld(sPx, o.vi);
-        o.pa = X::sel(bottom(), X::splat(real(1)), px);
-        o.pb = X::sel(bottom(), px, X::splat(real(1)));
+        const VI one = X::splati((int)(sZ + NX - sPx));
+        o.pa = X::lds_ld(sPx, X::seli(bottom(), one, o.vi));
+        o.pb = X::lds_ld(sPx, X::seli(bottom(), o.vi, one));
         o.v = X::lds_ld(sV, o.vi);
     }
     // S~_m^-1 v = M' (D^-1 (M v)) with the block's packed factor in o
