@@ -16,7 +16,7 @@ NAMES = ["problem load", "residuals", "factor: Dt, Pu", "factor: blocks", "apply
 def main():
     import torch
     from deq_mpc_corl_amd import _lib
-    _lib.LIB_PATH = os.path.join(ROOT, "deq-mpc-corl_amd", "csrc", "build", "libmi_alqp_g4timing.so")
+    _lib.LIB_PATH = os.environ.get("G4_TIMING_LIB") or os.path.join(ROOT, "deq-mpc-corl_amd", "csrc", "build", "libmi_alqp_g4timing.so")
     from deq_mpc_corl_amd import synthetic_problem
     from deq_mpc_corl_amd.backend import default_backend
     be = default_backend()
