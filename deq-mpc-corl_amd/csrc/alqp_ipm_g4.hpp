@@ -418,12 +418,15 @@ struct Solver {
             // lanes without an F term read their P from the zero words behind sPu: fp = 0 there (F itself is finite data)
             const VI pxb = X::seli(f_ok, pblk * NX, X::splati((int)(sZ - sPx)));
             const VI pub = X::seli(f_ok, pblk * 4, X::splati((int)(sZ - sPu)));
+            // (P is fetched as ONE vector per lane row, element k on lane k, and spread by the row broadcast: a load per
+            //  column would be seventeen more LDS round trips in front of the chains)
+            const V pxv = X::lds_ld(sPx, pxb + rc);
+            const V puv = X::lds_ld(sPu, pub + X::mini(j, X::splati(NU - 1)));
             V fr[N], fp[N];
             G4_UNROLL
-            for (int k = 0; k < N; ++k) {
-                fr[k] = X::lds_ld(sF, fb + k);
-                fp[k] = fr[k] * (k < NX ? X::lds_ld(sPx, pxb + k) : X::lds_ld(sPu, pub + (k - NX)));
-            }
+            for (int k = 0; k < N; ++k) fr[k] = X::lds_ld(sF, fb + k);
+            X::template scale<0, NX>(fp, pxv, fr);
+            X::template scale<0, NU>(fp + NX, puv, fr + NX);
             fmac_rank<X, NX, N>(S, fr, fp);   // F P F'
             tick(11);
             // coupling rows: top fp[c] = A_{m-1}[r][c] P_{m-1}[c]; bottom P_m[r] A_m[c][r] (column r of A_m; none for block T-1)
@@ -448,7 +451,13 @@ struct Solver {
                 G4_UNROLL
                 for (int c = 0; c < NX; ++c) S[c] = S[c] + X::gather(S[c], other);
             }
-            ldl<0>(S, Mrow, dprev, dg, mv, live);
+            VI bad = X::splati(0);
+            ldl<0>(S, Mrow, dprev, dg, bad);
+            if (X::wave_any((bad != 0) & live)) {   // rare: record the first one (block * nx + column + 1)
+                G4_UNROLL
+                for (int c = 0; c < NX; ++c)
+                    infov = X::seli((infov == 0) & live & (((bad >> (NX - 1 - c)) & 1) != 0), mv * NX + (c + 1), infov);
+            }
             if (i < tw.dl) {   // the bottom chain has not started: it has no previous block
                 G4_UNROLL
                 for (int k = 0; k < NX; ++k) { Mrow[k] = keep(!bot, Mrow[k]); dprev[k] = keep(!bot, dprev[k]); }
@@ -473,16 +482,16 @@ struct Solver {
     // and on the leading columns of the identity that becomes M = L^-1 (X::pivot, one block). Column C of M below the
     // diagonal is -L[:, C] at this point; M's unit diagonal is never read (nor stored) and is not formed.
     template <int C>
-    G4_FN void ldl(V *S, V *Mrow, V *dinv, const V &dg, const VI &mv, const VM &live) {
+    G4_FN void ldl(V *S, V *Mrow, V *dinv, const V &dg, VI &bad) {
         if constexpr (C < NX) {
             const V d = X::template bcast<C>(S[C] + dg);
-            infov = X::seli((infov == 0) & live & !(d > zero()), mv * NX + (C + 1), infov);
+            bad = bad + bad + X::seli(d > zero(), X::splati(0), X::splati(1));   // a shift register of the non-positive pivots
             const V di = X::rcp(X::absv(d));
             dinv[C] = di;
             const V nl = keep(r > C, -(S[C] * di));
             Mrow[C] = nl;
             if constexpr (NX > 1) X::template pivot<C, NX>(S, Mrow, nl);
-            ldl<C + 1>(S, Mrow, dinv, dg, mv, live);
+            ldl<C + 1>(S, Mrow, dinv, dg, bad);
         }
     }
 
@@ -742,7 +751,7 @@ struct Solver {
         for (int i = 0; i < SL; ++i) {
             const V d = dv[i];
             V s = X::sel(d == zero(), X::splat(real(1)),
-                         X::sel(d < zero(), -v[i] / d, X::sel(d != d, d, X::splat(real(INFINITY)))));
+                         X::sel(d < zero(), -(v[i] * X::rcp(d)), X::sel(d != d, d, X::splat(real(INFINITY)))));
             s = X::sel(mq(i), s, X::splat(real(INFINITY)));
             nf = nf | (s != s);
             mn = X::sel(s < mn, s, mn);

@@ -90,6 +90,11 @@ struct EmuX {
             for (int l = 0; l < W; ++l) acc[i].v[l] = std::fma(old.v[(l & 48) + K], ms.v[l], old.v[l]);
         }
     }
+    template <int K0, int C> static void scale(V *out, const V &x, const V *m) {
+        const V xs = x;
+        for (int i = 0; i < C; ++i) for (int l = 0; l < W; ++l) out[i].v[l] = std::fma(xs.v[(l & 48) + K0 + i], m[i].v[l], T0());
+    }
+    static real T0() { return real(0); }
     // the whole-matrix blocks of the GPU policy (one asm statement each there), in their order of operations
     static constexpr int rank_max(int na) { return (30 - na) / 2 < 8 ? (30 - na) / 2 : 8; }
     template <int NA, int NT> static void rank(V *acc, const V *x, const V *m) {
@@ -130,16 +135,24 @@ struct EmuX {
     static void gfence() {}
     static void sched_fence() {}
     static void launder(VI &) {}
-    static real wave_sum(const V &a) {   // the GPU's butterfly order (xor 32, 16, .., 1), so that sums round alike
+    // the GPU's order: inclusive scan inside each 16-lane row (shift 1, 2, 4, 8), lane 15 of rows 0 / 2 into rows 1 / 3,
+    // lane 31 into the upper half; lane 63 holds the result
+    template <class OP> static real wave_reduce(const V &a, OP op, bool sum) {
         V t = a;
-        for (int o = 32; o > 0; o >>= 1) { V n; for (int l = 0; l < W; ++l) n.v[l] = t.v[l] + t.v[l ^ o]; t = n; }
-        return t.v[0];
+        for (int s = 1; s < 16; s <<= 1) {
+            V n = t;
+            for (int l = 0; l < W; ++l) {
+                if ((l & 15) >= s) n.v[l] = op(t.v[l], t.v[l - s]);
+                else if (sum) n.v[l] = op(t.v[l], real(0));
+            }
+            t = n;
+        }
+        { V n = t; for (int l = 0; l < W; ++l) { const int row = l >> 4; if (row == 1 || row == 3) n.v[l] = op(t.v[l], t.v[(row - 1) * 16 + 15]); else if (sum) n.v[l] = op(t.v[l], real(0)); } t = n; }
+        { V n = t; for (int l = 0; l < W; ++l) { if (l >= 32) n.v[l] = op(t.v[l], t.v[31]); else if (sum) n.v[l] = op(t.v[l], real(0)); } t = n; }
+        return t.v[63];
     }
-    static real wave_min(const V &a) {
-        V t = a;
-        for (int o = 32; o > 0; o >>= 1) { V n; for (int l = 0; l < W; ++l) n.v[l] = (t.v[l ^ o] < t.v[l]) ? t.v[l ^ o] : t.v[l]; t = n; }
-        return t.v[0];
-    }
+    static real wave_sum(const V &a) { return wave_reduce(a, [](real x, real y) { return x + y; }, true); }
+    static real wave_min(const V &a) { return wave_reduce(a, [](real x, real y) { return (y < x) ? y : x; }, false); }
     static bool wave_any(const VM &m) { for (int l = 0; l < W; ++l) if (m.v[l]) return true; return false; }
     static void store4(real *sc, real a, real b, real c, real d) { sc[0] = a; sc[1] = b; sc[2] = c; sc[3] = d; }
     template <class A>

@@ -97,3 +97,27 @@ def test_resident_kernel_emulated_every_horizon(T, dims):
     b = emu.backward("f64", args[0], args[2], orc["lams"], orc["slacks"], gbar)
     for u, v in zip(a, b):
         assert np.abs(u - v).max() < 1e-8 * max(1.0, np.abs(u).max())
+
+
+def test_resident_kernel_emulated_reports_a_non_positive_pivot():
+    """A stage with negative curvature makes a pivot of the Schur complement non-positive: the kernel replaces it by
+    its magnitude and reports the first one as block * nx + column + 1, like the oracle. The top chain of the twisted
+    factorisation meets exactly the pivots of the oracle's top-down elimination, so a bad stage in the first half gives
+    the same index; a bad stage in the second half is met from below, through different (equally valid) pivots - the
+    flag is raised, its index is the twisted order's own."""
+    import torch
+    from deq_mpc_corl_amd import synthetic_problem
+    from oracle import ipm_py
+    from tests.emu import ipm_g4_emu_py as emu
+    T, nx, nu = 12, 4, 2
+    p = synthetic_problem(3, T, nx, nu, seed=3, dtype=torch.float64, device="cpu")
+    Qd = p.Qd.numpy().copy()
+    Qd[1, 3, :nx] = -50.0        # instance 1: stage 3 (top chain)
+    Qd[2, 9, :nx] = -50.0        # instance 2: stage 9 (bottom chain)
+    c = lambda a: a.numpy()
+    args = (Qd, c(p.q), c(p.F), c(p.c), c(p.x0), c(p.u_hi), c(p.u_lo))
+    got = emu.forward("f64", *args, exit_mode="fixed", max_iter=2)
+    orc = ipm_py.forward("f64", *args, solver=0, exit_mode=1, max_iter=2)
+    assert int(got["info"][0]) == 0 and int(orc["info"][0]) == 0
+    assert int(got["info"][1]) == int(orc["info"][1]) != 0
+    assert int(got["info"][2]) != 0 and int(orc["info"][2]) != 0

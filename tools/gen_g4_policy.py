@@ -107,6 +107,22 @@ def pivot(nx, c, t):
             "        asm(" + "\n            ".join(lines) + f"\n            : {outs} : \"v\"(S[{c}]), \"v\"(nl));\n    }}\n")
 
 
+def scale(n, t):
+    """out[i] = bcast_{K0+i}(x) * m[i]: a vector held one element per lane scales n registers (f64: zero + fmac, the
+    double-precision ALU has no DPP multiply; f32: v_mul_f32_dpp)."""
+    lines = ['"s_nop 1\\n\\t"']
+    for i in range(n):
+        if t == "double":
+            lines.append(f'"v_mov_b64 %{i}, 0\\n\\t"')
+            lines.append(f'"v_fmac_f64_dpp %{i}, %{n}, %{n + 1 + i} row_newbcast:%{2 * n + 1}+{i}{TAIL}"')
+        else:
+            lines.append(f'"v_mul_f32_dpp %{i}, %{n}, %{n + 1 + i} row_newbcast:%{2 * n + 1}+{i}{TAIL}"')
+    outs = ", ".join(f'"=&v"(out[{i}])' for i in range(n))
+    ins = ", ".join(['"v"(x)'] + [f'"v"(m[{i}])' for i in range(n)] + ['"n"(K0)'])
+    return (f"    template <int K0> static G4_FN void scale_{n}({t} *out, const {t} &x, const {t} *m) {{\n"
+            "        asm(" + "\n            ".join(lines) + f"\n            : {outs} : {ins});\n    }}\n")
+
+
 def ztri(nx, k0, k1, t):
     """Z[c] += bcast_c(M[k]) * s[k] for k0 <= k < k1, c > k: the strictly-lower part of Z = S M' in two blocks."""
     lo = k0 + 1                       # accumulators Z[lo .. nx)
@@ -248,16 +264,44 @@ TAILSRC = r'''    // memory
     static G4_FN void fence() { asm volatile("" ::: "memory"); }
     static G4_FN void gfence() { __syncthreads(); }
     static G4_FN void sched_fence() { __builtin_amdgcn_sched_barrier(0); }
-    static G4_FN real wave_sum(real v) {
-        _Pragma("unroll") for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-        return first(v);
+    // Wave reductions on the DPP network, no LDS round trips: an inclusive scan inside each 16-lane row (row_shr 1, 2,
+    // 4, 8), then lane 15 of rows 0 / 2 into rows 1 / 3 (row_bcast15), then lane 31 into the upper half (row_bcast31):
+    // lane 63 holds the result. (These are compiler-visible DPP moves of values the C++ code computed - hazards are
+    // padded by hipcc - unlike the asm chains; the shuffle version cost six exposed ds_bpermute round trips each.)
+    template <int CTRL, int ROWS, bool ZFILL> static G4_FN float dpp_mov(float old, float src) {
+        return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, src),
+                                                                      CTRL, ROWS, 0xf, ZFILL));
     }
+    template <int CTRL, int ROWS, bool ZFILL> static G4_FN double dpp_mov(double old, double src) {
+        const long long o = __builtin_bit_cast(long long, old), b = __builtin_bit_cast(long long, src);
+        const int lo = __builtin_amdgcn_update_dpp((int)(o & 0xffffffffll), (int)(b & 0xffffffffll), CTRL, ROWS, 0xf, ZFILL);
+        const int hi = __builtin_amdgcn_update_dpp((int)(o >> 32), (int)(b >> 32), CTRL, ROWS, 0xf, ZFILL);
+        return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
+    }
+    static G4_FN float lane63(float v) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63)); }
+    static G4_FN double lane63(double v) {
+        const long long b = __builtin_bit_cast(long long, v);
+        const int lo = __builtin_amdgcn_readlane((int)(b & 0xffffffffll), 63), hi = __builtin_amdgcn_readlane((int)(b >> 32), 63);
+        return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
+    }
+    static G4_FN real wave_sum(real v) {
+        v += dpp_mov<0x111, 0xf, true>(real(0), v);
+        v += dpp_mov<0x112, 0xf, true>(real(0), v);
+        v += dpp_mov<0x114, 0xf, true>(real(0), v);
+        v += dpp_mov<0x118, 0xf, true>(real(0), v);
+        v += dpp_mov<0x142, 0xa, false>(real(0), v);
+        v += dpp_mov<0x143, 0xc, false>(real(0), v);
+        return lane63(v);
+    }
+    static G4_FN real min2(real a, real b) { return (b < a) ? b : a; }
     static G4_FN real wave_min(real v) {
-        _Pragma("unroll") for (int o = 32; o > 0; o >>= 1) {
-            const real w = __shfl_xor(v, o, 64);
-            v = (w < v) ? w : v;
-        }
-        return first(v);
+        v = min2(v, dpp_mov<0x111, 0xf, false>(v, v));
+        v = min2(v, dpp_mov<0x112, 0xf, false>(v, v));
+        v = min2(v, dpp_mov<0x114, 0xf, false>(v, v));
+        v = min2(v, dpp_mov<0x118, 0xf, false>(v, v));
+        v = min2(v, dpp_mov<0x142, 0xa, false>(v, v));
+        v = min2(v, dpp_mov<0x143, 0xc, false>(v, v));
+        return lane63(v);
     }
     static G4_FN bool wave_any(bool m) { return __builtin_amdgcn_ballot_w64(m) != 0; }
     static G4_FN void store4(real *sc, real a, real b, real c, real d) {
@@ -288,6 +332,8 @@ def main():
             body += multi(n, t) + selfu(n, t)
         for n in range(1, 14):   # 2 accumulators + 2 n inputs + K: the 30-operand limit of an asm statement
             body += vec(n, t)
+        for n in range(1, 15):
+            body += scale(n, t)
         for nx in NXS:
             for nt in range(1, min(8, (30 - nx) // 2) + 1):
                 body += rank(nx, nt, t)
@@ -329,6 +375,7 @@ def main():
     body += dispatcher("multi", "real *acc, const real &x, const real &m", "acc, x, m", 16)
     body += dispatcher("vec", "real &acc, const real *x, const real *m", "acc, x, m", 13, ("K0", "acc, x + 13, m + 13"))
     body += dispatcher("self", "real *acc, const real &m", "acc, m", 16)
+    body += dispatcher("scale", "real *out, const real &x, const real *m", "out, x, m", 14)
     out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "deq-mpc-corl_amd", "csrc",
                        "alqp_ipm_g4_gpu.hpp")
     with open(out, "w") as f:
