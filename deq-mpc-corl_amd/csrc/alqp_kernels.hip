@@ -148,7 +148,12 @@ __device__ inline unsigned opaque_zero() {
 // Measured (profiles/r02/experiments): fp64 is faster uncapped at every batch the team kernels see (B = 200: 1.27 ->
 // 1.22 ms, B = 2048: 3.43 -> 2.85 ms); fp32 only while there is at most one wavefront per SIMD anyway (B = 200: 0.84 ->
 // 0.80 ms, B = 1024: 0.91 -> 0.87 ms; B = 2048: 1.07 against 1.71 ms). dispatch_solve() picks accordingly.
-template <typename real, int NX, int NU, bool TRACE, int OCC = 2>
+// The TRACE instantiations (tests only) are never capped: with their extra live pointers the capped fp64 builds spill ~70-150
+// registers, and this hipcc (ROCm 7.2) can place such a spill store at the head of a divergent loop's exit block IN FRONT OF the
+// `s_or_b64 exec` that re-enables the lanes - the store then runs with EXEC = 0 and the reload returns stale scratch. Seen once
+// (k_solve_lin<double,12,4,true,2>: the zs base offset spilled after the `for (e = li; e < T*N; e += G)` load loop, every row
+// of the returned z one repeated value); the uncapped builds have no spills (checked per kernel: tools/spill_report.py).
+template <typename real, int NX, int NU, bool TRACE, int OCC = TRACE ? 1 : 2>
 __global__ __launch_bounds__(64, OCC) void k_solve_lin(SolveArgs<real> a, TraceArgs<real> tr) {
     if (a.skip && *a.skip != 0.0) return;  // block-uniform, before any barrier
     using C = Cfg<real, NX, NU>;

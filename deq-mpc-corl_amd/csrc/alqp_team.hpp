@@ -81,9 +81,27 @@ __device__ inline double fabs_(double a) { return __builtin_fabs(a); }
 __device__ inline float fmax_(float a, float b) { return __builtin_fmaxf(a, b); }
 __device__ inline double fmax_(double a, double b) { return __builtin_fmax(a, b); }
 __device__ inline float rsqrt_(float p) { return __builtin_amdgcn_rsqf(p); }
-__device__ inline double rsqrt_(double p) { return 1.0 / __builtin_sqrt(p); }
+// fp64: hardware estimate + two coupled Newton steps (g -> sqrt p, h -> 1 / (2 sqrt p)), ~1 ulp, 9 instructions. The
+// correctly rounded 1.0 / sqrt(p) is a 30-instruction dependent sequence (scaled square root, then an IEEE division)
+// on the critical path of every pivot of the panel: half of a stage's cycles at the reference's batch size.
+__device__ inline double rsqrt_(double p) {
+    const double y = __builtin_amdgcn_rsq(p);
+    double g = p * y, h = 0.5 * y;
+    double r = __builtin_fma(-h, g, 0.5);
+    g = __builtin_fma(g, r, g);
+    h = __builtin_fma(h, r, h);
+    r = __builtin_fma(-h, g, 0.5);
+    h = __builtin_fma(h, r, h);
+    return h + h;
+}
 __device__ inline float rcp_(float p) { return __builtin_amdgcn_rcpf(p); }
-__device__ inline double rcp_(double p) { return 1.0 / p; }
+// fp64: hardware estimate + two Newton steps (~1 ulp) instead of the IEEE division sequence
+__device__ inline double rcp_(double p) {
+    double r = __builtin_amdgcn_rcp(p);
+    r = __builtin_fma(__builtin_fma(-p, r, 1.0), r, r);
+    r = __builtin_fma(__builtin_fma(-p, r, 1.0), r, r);
+    return r;
+}
 
 // v if d >= 0 else +0, without a lane-mask compare (loop-invariant compares get hoisted
 // into SGPR pairs by the compiler and then spilled: 2 SGPRs per unrolled index)
