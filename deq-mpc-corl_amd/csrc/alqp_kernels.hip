@@ -142,6 +142,9 @@ __device__ inline unsigned opaque_zero() {
 }
 
 #if ALQP_BUILD_MAIN
+#ifdef ALQP_PHASE_TIMING
+__device__ unsigned long long g_team_cycles[8];   // debug build only (tools/team_timing.py)
+#endif
 // ---- fused LinDx solve -------------------------------------------------------------
 // OCC: wavefronts per SIMD the register allocation is capped for. 2 (256 registers) lets a CU hold the 8 teams its
 // LDS has room for, but costs 80 B (fp32) / 252 B (fp64) of scratch per lane at (13,4); 1 (no cap) has no scratch.
@@ -167,6 +170,10 @@ __global__ __launch_bounds__(64, OCC) void k_solve_lin(SolveArgs<real> a, TraceA
     const int T = a.T, M = C::M(T), neq = T * NX;
 
     Team<real, NX, NU> tm;
+#ifdef ALQP_PHASE_TIMING
+    for (int i = 0; i < 8; ++i) tm.tacc[i] = 0;
+    tm.stamp(-1);
+#endif
     tm.init(smem + (size_t)team * C::team_words(T) + opaque_zero(), li, team * G, T, b);
     tm.gQd = a.Qd + (size_t)b * T * N;
     tm.gq = a.q + (size_t)b * T * N;
@@ -204,7 +211,13 @@ __global__ __launch_bounds__(64, OCC) void k_solve_lin(SolveArgs<real> a, TraceA
             real *tg = nullptr;
             if constexpr (TRACE) tg = (tr.g && active) ? tr.g + ((size_t)step_id * a.B + b) * T * N : nullptr;
             tm.forward_sweep(tg);
+#ifdef ALQP_PHASE_TIMING
+            tm.stamp(-1);
+#endif
             tm.backward_sweep();
+#ifdef ALQP_PHASE_TIMING
+            tm.stamp(4);
+#endif
             if constexpr (TRACE) {
                 if (tr.d && active) {
                     real *td = tr.d + ((size_t)step_id * a.B + b) * T * N;
@@ -213,6 +226,9 @@ __global__ __launch_bounds__(64, OCC) void k_solve_lin(SolveArgs<real> a, TraceA
             }
             real ph[20];
             tm.template merit_candidates<20>(ph, false);
+#ifdef ALQP_PHASE_TIMING
+            tm.stamp(5);
+#endif
             // first argmin, a NaN wins like torch.min (al_utils.py:634)
             int kbest = 0;
             real best = ph[0];
@@ -267,6 +283,9 @@ __global__ __launch_bounds__(64, OCC) void k_solve_lin(SolveArgs<real> a, TraceA
             for (int e = li; e < T * N; e += G) tm.zs[e] += alpha * tm.ds[e];
             for (int e = li; e < neq; e += G) tm.req[e] += alpha * tm.seq[e];
             wave_sync();
+#ifdef ALQP_PHASE_TIMING
+            tm.stamp(6);
+#endif
             phi_prev = best;  // merit <- new_merit even when rejected (al_utils.py:569)
             if (ref_exit) {   // al_utils.py:551-564, the same test alqp_exit_test takes between launches
                 const real r1 = tm.rplus2();
@@ -290,6 +309,11 @@ __global__ __launch_bounds__(64, OCC) void k_solve_lin(SolveArgs<real> a, TraceA
         bad |= !(v - v == real(0));
     }
     bad = team_or<G>(bad);
+#ifdef ALQP_PHASE_TIMING
+    tm.stamp(7);
+    if (lane == 0)
+        for (int i = 0; i < 8; ++i) atomicAdd(&g_team_cycles[i], tm.tacc[i]);
+#endif
     if (active) {
         for (int e = li; e < T * N; e += G) gz[e] = tm.zs[e];
         if ((a.flags & ALQP_SAVE_FACTOR) && a.factor) {
@@ -1860,6 +1884,18 @@ int alqp_backward_ws_f64(const AlqpDims *dims, void *workspace, size_t ws_bytes,
 
 }  // extern "C"
 #endif  // ALQP_BUILD_MAIN
+
+#if defined(ALQP_PHASE_TIMING) && ALQP_BUILD_MAIN
+// debug build only: read (and optionally reset) the per-phase cycle counters of k_solve_lin (team kernel)
+extern "C" int alqp_debug_team_cycles(unsigned long long *out8, int reset) {
+    if (out8 && hipMemcpyFromSymbol(out8, HIP_SYMBOL(alqp::g_team_cycles), 8 * sizeof(unsigned long long)) != hipSuccess) return -1;
+    if (reset) {
+        unsigned long long z[8] = {0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(alqp::g_team_cycles), z, sizeof(z)) != hipSuccess) return -1;
+    }
+    return 0;
+}
+#endif
 
 #if defined(ALQP_PHASE_TIMING) && ALQP_QUAD_F32
 // debug build only: read (and optionally reset) the per-phase cycle counters of k_solve_lin_quad

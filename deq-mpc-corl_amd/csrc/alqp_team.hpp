@@ -195,6 +195,23 @@ struct Team {
     real obs_r2;
     bool no_init;       // state-estimator variant: no initial-state rows, zero cost gradient on u (al_utils_se.py:186-200, 300-310)
 
+#ifdef ALQP_PHASE_TIMING
+    // debug build only (tools/team_timing.py): cycles per phase of the team kernel. Buckets: 0 stage inputs + gradient,
+    // 1 SYRK, 2 panel, 3 stage results, 4 backward sweep, 5 line-search merits, 6 pick + apply, 7 everything else
+    unsigned long long tacc[8], tlast;
+    __device__ __forceinline__ void stamp(int bucket) {
+        unsigned long long now;
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt vmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(now)::"memory");
+        __builtin_amdgcn_sched_barrier(0);
+        if (bucket >= 0) tacc[bucket] += now - tlast;
+        tlast = now;
+    }
+#define TSTAMP(b) stamp(b)
+#else
+#define TSTAMP(b)
+#endif
+
     // `lds_team` must not be provably wave-uniform (see the kernels): uniform LDS reads
     // get scalarised by the compiler into ds_read + v_readfirstlane + SGPR-spill chains.
     __device__ void init(real *lds_team, int lane_in_team, int team_base_, int T_, int b_) {
@@ -302,6 +319,7 @@ struct Team {
         if (isW) lan = lams[wr];
         // Sb may hold s_eq of the previous Newton step: restore its constant zero rows
         for (int e = li; e < RB * NP; e += G) Sb[e] = 0;
+        TSTAMP(7);
         for (int t = 0; t < T; ++t) {
             const bool dyn = t < T - 1;
             const real Qv = Qn, qv = qn, cv = cn, la = lan, lb = lbn;
@@ -403,6 +421,7 @@ struct Team {
                 gs[hi] = g;
                 if (g_out) g_out[t * N + hi] = g;
             }
+            TSTAMP(0);
             // ---- SYRK phase: Hs = rho Ft Ft' - Sb Sb' on 2x2 blocks (lower triangle)
             if (isBlk) {
                 real a00 = 0, a01 = 0, a10 = 0, a11 = 0;
@@ -438,6 +457,7 @@ struct Team {
                 Hs[(i0 + 1) * HP + j0] = a10; Hs[(i0 + 1) * HP + j0 + 1] = a11;
             }
             wave_sync();
+            TSTAMP(1);
             // ---- diagonal of H_tt on top of the SYRK result (same lane order: in-order LDS)
             if (isH) Hs[hi * HP + hi] += D;
             if constexpr (NX >= 3) {
@@ -477,6 +497,7 @@ struct Team {
                 // rows stay exactly 0 left of their diagonal (X is upper triangular)
                 l[j] = acc * rsqrt_(fabs_(p));  // |p|: modified Cholesky on a non-positive pivot (flagged in info)
             }
+            TSTAMP(2);
             // ---- stage results
             if (isW || isY) {
                 real *dst = isW ? Sb + wr * NP : Sb + N * NP;
@@ -497,6 +518,7 @@ struct Team {
                 for (int k = 0; k < N; ++k) Xr[k > ui ? k : ui] = l[k];
             }
             wave_sync();
+            TSTAMP(3);
         }
     }
 
