@@ -48,8 +48,13 @@ __device__ __forceinline__ real *lds_base() {
     return (real *)reinterpret_cast<__attribute__((address_space(3))) real *>(2 * sizeof(real));
 }
 
+#ifdef ALQP_G4_WPE
+#define G4_WPE __attribute__((amdgpu_waves_per_eu(1, 1)))
+#else
+#define G4_WPE
+#endif
 template <typename real, int NX, int NU>
-__global__ __launch_bounds__(64, kWavesPerSimd<real>) void k_ipm_g4(const IpmArgs<real> a) {
+__global__ __launch_bounds__(64, kWavesPerSimd<real>) G4_WPE void k_ipm_g4(const IpmArgs<real> a) {
     const int b = blockIdx.x;
     if (b >= a.B) return;
     Solver<real, NX, NU, kSlots, GpuX<real>> S(a, lds_base<real>(), b);

@@ -465,8 +465,11 @@ struct Solver {
             tick(14);
             const VI mo = X::seli(bot, X::splati((tw.MB0 + i) * MSZ), X::splati(i * MSZ));
             const VM st_ok = ((lane & 16) == 0) & mXr() & live & (!bot | um(!is_mid));
-            G4_UNROLL
-            for (int k = 0; k + 1 < NX; ++k) X::lds_st(sM, mo + (((rc * (rc - 1)) >> 1) + k), Mrow[k], st_ok & (r > k));
+            // Row r of M (entries k < r) is packed at r (r - 1) / 2. Every row lane stores its NX - 1 registers from that
+            // offset in DESCENDING k under one predicate: the entries k >= r (exact zeros) land in later rows' cells, whose
+            // owners write them afterwards (their k is smaller) - no per-entry predicate. Within one k the lanes' addresses
+            // differ (row offsets are distinct from row 1 on; row 0 has no entries and stays out).
+            if constexpr (NX > 1) X::template lds_st_desc<NX - 1>(sM, mo + ((rc * (rc - 1)) >> 1), Mrow, st_ok & (r > 0));
             const VM d_ok = ((lane & 31) == 0) & live & (!bot | um(!is_mid));   // 1/d_k is uniform inside a half: one lane stores all
             G4_UNROLL
             for (int k = 0; k < NX; ++k) X::lds_st(sM, mo + (NXL + k), dprev[k], d_ok);

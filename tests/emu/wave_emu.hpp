@@ -129,6 +129,9 @@ struct EmuX {
     static V lds_ld(const real *p, const VI &idx) { V o; for (int l = 0; l < W; ++l) o.v[l] = p[idx.v[l]]; return o; }
     static V lds_ldu(const real *p, int idx) { return splat(p[idx]); }
     static void lds_st(real *p, const VI &idx, const V &v, const VM &m) { for (int l = 0; l < W; ++l) if (m.v[l]) p[idx.v[l]] = v.v[l]; }
+    template <int CNT> static void lds_st_desc(real *p, const VI &idx0, const V *v, const VM &m) {
+        for (int k = CNT - 1; k >= 0; --k) for (int l = 0; l < W; ++l) if (m.v[l]) p[idx0.v[l] + k] = v[k].v[l];
+    }
     static V g_ld(const real *p, const VI &idx, const VM &m) { V o; for (int l = 0; l < W; ++l) o.v[l] = m.v[l] ? p[idx.v[l]] : real(0); return o; }
     static void g_st(real *p, const VI &idx, const V &v, const VM &m) { for (int l = 0; l < W; ++l) if (m.v[l]) p[idx.v[l]] = v.v[l]; }
     static void fence() {}

@@ -247,6 +247,16 @@ TAILSRC = r'''    // memory
     static G4_FN V lds_ld(const real *p, VI idx) { return p[idx]; }
     static G4_FN V lds_ldu(const real *p, int idx) { return p[idx]; }
     static G4_FN void lds_st(real *p, VI idx, V v, VM m) { if (m) p[idx] = v; }
+    // v[CNT-1] -> p[idx0 + CNT-1] first, ..., v[0] -> p[idx0] last, under ONE lane predicate and in exactly this order (the
+    // fences stop hipcc from reordering or pairing the stores: lanes overwrite each other's cells on purpose, see factor())
+    template <int CNT> static G4_FN void lds_st_desc(real *p, VI idx0, const V *v, VM m) {
+        if (m) {
+            _Pragma("unroll") for (int k = CNT - 1; k >= 0; --k) {
+                p[idx0 + k] = v[k];
+                asm volatile("" ::: "memory");
+            }
+        }
+    }
     // global accesses as uniform base + 32-bit byte offset (the saddr form: no 64-bit address per lane and access)
     static G4_FN V g_ld(const real *p, VI idx, VM m) {
         return m ? *reinterpret_cast<const real *>(reinterpret_cast<const char *>(p) + (unsigned)idx * (unsigned)sizeof(real)) : real(0);
