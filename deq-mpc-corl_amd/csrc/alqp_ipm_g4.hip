@@ -53,23 +53,34 @@ __device__ __forceinline__ real *lds_base() {
 #else
 #define G4_WPE
 #endif
-template <typename real, int NX, int NU>
+template <typename real, int NX, int NU, bool FULLT>
 __global__ __launch_bounds__(64, kWavesPerSimd<real>) G4_WPE void k_ipm_g4(const IpmArgs<real> a) {
     const int b = blockIdx.x;
     if (b >= a.B) return;
-    Solver<real, NX, NU, kSlots, GpuX<real>> S(a, lds_base<real>(), b);
+    Solver<real, NX, NU, kSlots, GpuX<real>, FULLT> S(a, lds_base<real>(), b);
     S.run_forward();
 }
 
-template <typename real, int NX, int NU>
+template <typename real, int NX, int NU, bool FULLT>
 __global__ __launch_bounds__(64, kWavesPerSimd<real>) void k_ipm_g4_backward(const IpmArgs<real> a, const real *lams, const real *slacks) {
     const int b = blockIdx.x;
     if (b >= a.B) return;
-    Solver<real, NX, NU, kSlots, GpuX<real>> S(a, lds_base<real>(), b);
+    Solver<real, NX, NU, kSlots, GpuX<real>, FULLT> S(a, lds_base<real>(), b);
     S.run_backward(lams, slacks);
 }
 
 constexpr size_t kLdsMax = 64 * 1024;
+
+template <typename real, int NX, int NU, bool FULLT>
+static int launch_kernel(const IpmArgs<real> &a, const real *lams, const real *slacks, bool backward, size_t lds, hipStream_t stream) {
+    const void *kf = backward ? reinterpret_cast<const void *>(k_ipm_g4_backward<real, NX, NU, FULLT>)
+                              : reinterpret_cast<const void *>(k_ipm_g4<real, NX, NU, FULLT>);
+    if (lds > 48 * 1024 && hipFuncSetAttribute(kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        return ALQP_E_LAUNCH;
+    if (backward) hipLaunchKernelGGL((k_ipm_g4_backward<real, NX, NU, FULLT>), dim3(a.B), dim3(64), lds, stream, a, lams, slacks);
+    else hipLaunchKernelGGL((k_ipm_g4<real, NX, NU, FULLT>), dim3(a.B), dim3(64), lds, stream, a);
+    return hipGetLastError() == hipSuccess ? 0 : ALQP_E_LAUNCH;
+}
 
 template <typename real, int NX, int NU>
 static int launch(IpmArgs<real> a, const real *lams, const real *slacks, bool backward, hipStream_t stream) {
@@ -80,13 +91,9 @@ static int launch(IpmArgs<real> a, const real *lams, const real *slacks, bool ba
     const size_t lds = (size_t)S::lds_words(a.T) * sizeof(real);
     if (lds > kLdsMax) return ALQP_E_UNSUPPORTED;
     a.ws_words = Lay<real, NX, NU>(a.T, true).total;
-    const void *kf = backward ? reinterpret_cast<const void *>(k_ipm_g4_backward<real, NX, NU>)
-                              : reinterpret_cast<const void *>(k_ipm_g4<real, NX, NU>);
-    if (lds > 48 * 1024 && hipFuncSetAttribute(kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-        return ALQP_E_LAUNCH;
-    if (backward) hipLaunchKernelGGL((k_ipm_g4_backward<real, NX, NU>), dim3(a.B), dim3(64), lds, stream, a, lams, slacks);
-    else hipLaunchKernelGGL((k_ipm_g4<real, NX, NU>), dim3(a.B), dim3(64), lds, stream, a);
-    return hipGetLastError() == hipSuccess ? 0 : ALQP_E_LAUNCH;
+    // the full horizon (every register slot holds a stage) has its own instantiation
+    return a.T == S::TMAX ? launch_kernel<real, NX, NU, true>(a, lams, slacks, backward, lds, stream)
+                          : launch_kernel<real, NX, NU, false>(a, lams, slacks, backward, lds, stream);
 }
 
 template <typename real>

@@ -83,7 +83,7 @@ G4_FN void fmac_rank(V *acc, const V *x, const V *m) {
     }
 }
 
-template <typename real, int NX, int NU, int SL, class X>
+template <typename real, int NX, int NU, int SL, class X, bool FULLT = false>
 struct Solver {
     using V = typename X::V;
     using VI = typename X::VI;
@@ -188,7 +188,11 @@ struct Solver {
     }
 
     G4_FN VI tof(int i) const { return g + 4 * i; }
-    G4_FN VM vs(int i) const { return tof(i) < T; }
+    // (FULLT: the launcher saw T == 4 * SL - every slot holds a stage and the per-slot validity masks fold away, +1.4 %)
+    G4_FN VM vs(int i) const {
+        if constexpr (FULLT) return um(true);
+        else return tof(i) < T;
+    }
     G4_FN VM mx(int i) const { return vs(i) & mXr(); }
     G4_FN VM mq(int i) const { return vs(i) & mQ(); }
     G4_FN VM mu(int i) const { return vs(i) & mU(); }

@@ -10,10 +10,10 @@
 
 using alqp_ipm::IpmArgs;
 
-template <typename real, int NX, int NU>
-static int run(const IpmArgs<real> &a0, const real *lams, const real *slacks, int backward) {
+template <typename real, int NX, int NU, bool FULLT>
+static int run_as(const IpmArgs<real> &a0, const real *lams, const real *slacks, int backward) {
     constexpr int SL = 5;
-    using S = alqp_ipm_g4::Solver<real, NX, NU, SL, wave_emu::EmuX<real>>;
+    using S = alqp_ipm_g4::Solver<real, NX, NU, SL, wave_emu::EmuX<real>, FULLT>;
     if (a0.T > S::TMAX || a0.T < 2) return -2;
     IpmArgs<real> a = a0;
     a.ws_words = alqp_ipm::Lay<real, NX, NU>(a.T, true).total;
@@ -25,6 +25,11 @@ static int run(const IpmArgs<real> &a0, const real *lams, const real *slacks, in
         else s.run_forward();
     }
     return 0;
+}
+// like the HIP launcher: the full horizon (T = 4 * SL) has its own instantiation
+template <typename real, int NX, int NU>
+static int run(const IpmArgs<real> &a, const real *lams, const real *slacks, int backward) {
+    return a.T == 20 ? run_as<real, NX, NU, true>(a, lams, slacks, backward) : run_as<real, NX, NU, false>(a, lams, slacks, backward);
 }
 
 template <typename real>
