@@ -292,24 +292,24 @@ struct Solver {
         return keep(mU(), X::gather(c, (lane & 48) + j) + X::gather(c, (lane & 48) + 4 + j));
     }
 
-    // out (stage m, lanes r < nx) = F_{m-1} [x_{m-1} ; u_{m-1}]   (0 at m = 0); xs: state parts, c0: u in quarter 2
+    // out (stage m, lanes r < nx) = F_{m-1} [x_{m-1} ; u_{m-1}]   (0 at m = 0); xs: state parts, c0: u in quarter 2.
+    // The product is formed on the lanes of stage m-1 (its own x, u: no operand moves) and the RESULT moves down one stage.
     G4_FN void Fx(const V *xs, const V *c0, V *out) const {
-        V xp[SL], up[SL];
-        shift_down(xs, xp);
-        shift_down(c0, up);
+        V w[SL];
         G4_UNROLL
         for (int i = 0; i < SL; ++i) {
             const VI t = tof(i);
-            const VI tm = X::mini(X::maxi(t - 1, X::splati(0)), X::splati(T - 2));
-            const VI base = slotF(tm) * FSZ + rc * N;
+            const VI tc = X::mini(t, X::splati(T - 2));
+            const VI base = slotF(tc) * FSZ + rc * N;
             V fr[N];
             G4_UNROLL
             for (int k = 0; k < N; ++k) fr[k] = X::lds_ld(sF, base + k);
             V acc = zero();
-            fmac_row<X, 0, NX>(acc, xp[i], fr);
-            fmac_row<X, 8, NU>(acc, up[i], fr + NX);
-            out[i] = keep(mx(i) & (t > 0), acc);
+            fmac_row<X, 0, NX>(acc, xs[i], fr);
+            fmac_row<X, 8, NU>(acc, c0[i], fr + NX);
+            w[i] = keep(mx(i) & (t < T - 1), acc);
         }
+        shift_down(w, out);
     }
     // ox (lanes k < nx) = (F_t' yn)_k, ou (quarter 2) = (F_t' yn)_{nx+j}; yn = the next stage's multiplier slice
     G4_FN void FTy(const V *yn, V *ox, V *ou) const {
@@ -761,7 +761,7 @@ struct Solver {
                          X::sel(d < zero(), -(v[i] * X::rcp(d)), X::sel(d != d, d, X::splat(real(INFINITY)))));
             s = X::sel(mq(i), s, X::splat(real(INFINITY)));
             nf = nf | (s != s);
-            mn = X::sel(s < mn, s, mn);
+            mn = X::vmin(mn, s);   // (a NaN ratio is flagged through nf, not through the minimum)
         }
         if (X::wave_any(nf)) nanflag = 1;
         return X::wave_min(mn);

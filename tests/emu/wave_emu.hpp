@@ -155,7 +155,8 @@ struct EmuX {
         return t.v[63];
     }
     static real wave_sum(const V &a) { return wave_reduce(a, [](real x, real y) { return x + y; }, true); }
-    static real wave_min(const V &a) { return wave_reduce(a, [](real x, real y) { return (y < x) ? y : x; }, false); }
+    static real wave_min(const V &a) { return wave_reduce(a, [](real x, real y) { return std::fmin(x, y); }, false); }
+    static V vmin(const V &a, const V &b) { V o; for (int l = 0; l < W; ++l) o.v[l] = std::fmin(a.v[l], b.v[l]); return o; }
     static bool wave_any(const VM &m) { for (int l = 0; l < W; ++l) if (m.v[l]) return true; return false; }
     static void store4(real *sc, real a, real b, real c, real d) { sc[0] = a; sc[1] = b; sc[2] = c; sc[3] = d; }
     template <class A>

@@ -303,7 +303,9 @@ TAILSRC = r'''    // memory
         v += dpp_mov<0x143, 0xc, false>(real(0), v);
         return lane63(v);
     }
-    static G4_FN real min2(real a, real b) { return (b < a) ? b : a; }
+    static G4_FN float min2(float a, float b) { return __builtin_fminf(a, b); }     // v_min: one instruction (a NaN operand is
+    static G4_FN double min2(double a, double b) { return __builtin_fmin(a, b); }   // ignored; the callers flag NaNs separately)
+    static G4_FN V vmin(V a, V b) { return min2(a, b); }
     static G4_FN real wave_min(real v) {
         v = min2(v, dpp_mov<0x111, 0xf, false>(v, v));
         v = min2(v, dpp_mov<0x112, 0xf, false>(v, v));
