@@ -284,13 +284,11 @@ struct Solver {
         for (int i = 0; i < SL; ++i) out[i] = X::sel(g == 3, i < SL - 1 ? tmp[i < SL - 1 ? i + 1 : 0] : zero(), tmp[i]);
     }
     // control-register moves inside a row: u (quarter 2) -> quarters 0 and 1; (q0 -/+ q1) -> quarter 2
-    G4_FN V u_to_q(const V &c) const { return keep(mQ(), X::gather(c, (lane & 48) + 8 + j)); }
-    G4_FN V q_diff_to_u(const V &c) const {
-        return keep(mU(), X::gather(c, (lane & 48) + j) - X::gather(c, (lane & 48) + 4 + j));
-    }
-    G4_FN V q_sum_to_u(const V &c) const {
-        return keep(mU(), X::gather(c, (lane & 48) + j) + X::gather(c, (lane & 48) + 4 + j));
-    }
+    // (row shifts on the DPP network: quarter 0 = lanes 0-3, quarter 1 = 4-7, quarter 2 = 8-11 of every 16-lane row;
+    //  through ds_bpermute each of these was an exposed LDS round trip, ~95 of them per iteration)
+    G4_FN V u_to_q(const V &c) const { return keep(mQ(), X::sel(qd == 0, X::template rshl<8>(c), X::template rshl<4>(c))); }
+    G4_FN V q_diff_to_u(const V &c) const { return keep(mU(), X::template rshr<8>(c) - X::template rshr<4>(c)); }
+    G4_FN V q_sum_to_u(const V &c) const { return keep(mU(), X::template rshr<8>(c) + X::template rshr<4>(c)); }
 
     // out (stage m, lanes r < nx) = F_{m-1} [x_{m-1} ; u_{m-1}]   (0 at m = 0); xs: state parts, c0: u in quarter 2.
     // The product is formed on the lanes of stage m-1 (its own x, u: no operand moves) and the RESULT moves down one stage.

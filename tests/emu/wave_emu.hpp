@@ -138,6 +138,8 @@ struct EmuX {
     static void gfence() {}
     static void sched_fence() {}
     static void launder(VI &) {}
+    template <int N> static V rshl(const V &x) { V o; for (int l = 0; l < W; ++l) o.v[l] = ((l & 15) + N < 16) ? x.v[l + N] : real(0); return o; }
+    template <int N> static V rshr(const V &x) { V o; for (int l = 0; l < W; ++l) o.v[l] = ((l & 15) >= N) ? x.v[l - N] : real(0); return o; }
     // the GPU's order: inclusive scan inside each 16-lane row (shift 1, 2, 4, 8), lane 15 of rows 0 / 2 into rows 1 / 3,
     // lane 31 into the upper half; lane 63 holds the result
     template <class OP> static real wave_reduce(const V &a, OP op, bool sum) {

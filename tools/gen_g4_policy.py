@@ -294,6 +294,9 @@ TAILSRC = r'''    // memory
         const int lo = __builtin_amdgcn_readlane((int)(b & 0xffffffffll), 63), hi = __builtin_amdgcn_readlane((int)(b >> 32), 63);
         return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
     }
+    // moves inside a 16-lane row on the DPP network: lane l takes lane l + N (rshl) / l - N (rshr) of its row, 0 beyond it
+    template <int N> static G4_FN real rshl(real v) { return dpp_mov<0x100 + N, 0xf, true>(real(0), v); }
+    template <int N> static G4_FN real rshr(real v) { return dpp_mov<0x110 + N, 0xf, true>(real(0), v); }
     static G4_FN real wave_sum(real v) {
         v += dpp_mov<0x111, 0xf, true>(real(0), v);
         v += dpp_mov<0x112, 0xf, true>(real(0), v);
