@@ -292,40 +292,55 @@ struct Solver {
 
     // out (stage m, lanes r < nx) = F_{m-1} [x_{m-1} ; u_{m-1}]   (0 at m = 0); xs: state parts, c0: u in quarter 2.
     // The product is formed on the lanes of stage m-1 (its own x, u: no operand moves) and the RESULT moves down one stage.
+    // Both F products keep TWO operand sets: a slot's matrix entries are read while the previous chain runs (hipcc reuses
+    // one register set otherwise, and every chain starts with an exposed LDS round trip: 15 of them per pair of products).
+    G4_FN VI f_base(int i) const { return slotF(X::mini(tof(i), X::splati(T - 2))) * FSZ; }
     G4_FN void Fx(const V *xs, const V *c0, V *out) const {
-        V w[SL];
+        V w[SL], fr[2][N];
+        {
+            const VI base = f_base(0) + rc * N;
+            G4_UNROLL
+            for (int k = 0; k < N; ++k) fr[0][k] = X::lds_ld(sF, base + k);
+        }
         G4_UNROLL
         for (int i = 0; i < SL; ++i) {
-            const VI t = tof(i);
-            const VI tc = X::mini(t, X::splati(T - 2));
-            const VI base = slotF(tc) * FSZ + rc * N;
-            V fr[N];
-            G4_UNROLL
-            for (int k = 0; k < N; ++k) fr[k] = X::lds_ld(sF, base + k);
+            if (i + 1 < SL) {
+                const VI base = f_base(i + 1) + rc * N;
+                G4_UNROLL
+                for (int k = 0; k < N; ++k) fr[(i + 1) & 1][k] = X::lds_ld(sF, base + k);
+            }
             V acc = zero();
-            fmac_row<X, 0, NX>(acc, xs[i], fr);
-            fmac_row<X, 8, NU>(acc, c0[i], fr + NX);
-            w[i] = keep(mx(i) & (t < T - 1), acc);
+            fmac_row<X, 0, NX>(acc, xs[i], fr[i & 1]);
+            fmac_row<X, 8, NU>(acc, c0[i], fr[i & 1] + NX);
+            w[i] = keep(mx(i) & (tof(i) < T - 1), acc);
         }
         shift_down(w, out);
     }
     // ox (lanes k < nx) = (F_t' yn)_k, ou (quarter 2) = (F_t' yn)_{nx+j}; yn = the next stage's multiplier slice
     G4_FN void FTy(const V *yn, V *ox, V *ou) const {
+        V fx[NX], fu[NX];
+        {
+            const VI bx = f_base(0) + rc;
+            G4_UNROLL
+            for (int q = 0; q < NX; ++q) fx[q] = X::lds_ld(sF, bx + q * N);
+        }
         G4_UNROLL
         for (int i = 0; i < SL; ++i) {
             const VI t = tof(i);
-            const VI tc = X::mini(t, X::splati(T - 2));
-            const VI sb = slotF(tc) * FSZ;
-            const VI bx = sb + rc, bu = sb + NX + j;
-            V fc[NX];
-            G4_UNROLL
-            for (int q = 0; q < NX; ++q) fc[q] = X::lds_ld(sF, bx + q * N);
+            {
+                const VI bu = f_base(i) + NX + j;
+                G4_UNROLL
+                for (int q = 0; q < NX; ++q) fu[q] = X::lds_ld(sF, bu + q * N);
+            }
             V ax = zero();
-            fmac_row<X, 0, NX>(ax, yn[i], fc);
-            G4_UNROLL
-            for (int q = 0; q < NX; ++q) fc[q] = X::lds_ld(sF, bu + q * N);
+            fmac_row<X, 0, NX>(ax, yn[i], fx);
+            if (i + 1 < SL) {
+                const VI bx = f_base(i + 1) + rc;
+                G4_UNROLL
+                for (int q = 0; q < NX; ++q) fx[q] = X::lds_ld(sF, bx + q * N);
+            }
             V au = zero();
-            fmac_row<X, 0, NX>(au, yn[i], fc);
+            fmac_row<X, 0, NX>(au, yn[i], fu);
             ox[i] = keep(mx(i) & (t < T - 1), ax);
             ou[i] = keep(mu(i) & (t < T - 1), au);
         }
@@ -427,19 +442,23 @@ struct Solver {
             V fr[N], fp[N];
             G4_UNROLL
             for (int k = 0; k < N; ++k) fr[k] = X::lds_ld(sF, fb + k);
+            // the bottom chain's coupling columns (used after F P F'): read with this batch, under the rank-1 updates
+            int zs = tw.mid + i - tw.dl - 1;
+            zs = zs < 0 ? 0 : (zs > T - 2 ? T - 2 : zs);
+            const VI zb = X::splati(zs * FSZ) + rc;
+            V zraw[NX];
+            G4_UNROLL
+            for (int c = 0; c < NX; ++c) zraw[c] = X::lds_ld(sF, zb + c * N);
             X::template scale<0, NX>(fp, pxv, fr);
             X::template scale<0, NU>(fp + NX, puv, fr + NX);
             fmac_rank<X, NX, N>(S, fr, fp);   // F P F'
             tick(11);
             // coupling rows: top fp[c] = A_{m-1}[r][c] P_{m-1}[c]; bottom P_m[r] A_m[c][r] (column r of A_m; none for block T-1)
-            int zs = tw.mid + i - tw.dl - 1;
-            zs = zs < 0 ? 0 : (zs > T - 2 ? T - 2 : zs);
             const VM zb_ok = bot & live & (mv < T - 1);
-            const VI zb = X::splati(zs * FSZ) + rc;
             V zsrc[NX], Z[NX], zd[NX];
             G4_UNROLL
             for (int c = 0; c < NX; ++c) {
-                zsrc[c] = X::sel(bot, keep(zb_ok, X::lds_ld(sF, zb + c * N) * pxo), fp[c]);
+                zsrc[c] = X::sel(bot, keep(zb_ok, zraw[c] * pxo), fp[c]);
                 Z[c] = zsrc[c];
             }
             if constexpr (NX > 1) X::template ztri<NX>(Z, Mrow, zsrc);   // Z[r][c] = -(zsrc[c] + sum_{k<c} M[c][k] zsrc[k]), M[c][k] = lane c's Mrow[k]
