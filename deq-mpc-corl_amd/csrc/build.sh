@@ -7,7 +7,10 @@ set -euo pipefail
 cd "$(dirname "$0")"
 # -pragma-unroll-threshold: the panel loops of alqp_quad.hpp must be fully unrolled (register
 # arrays need static indices); the default threshold silently leaves them rolled.
-FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -I../../include -mllvm -pragma-unroll-threshold=1000000"
+# -O2, not -O3: these kernels run one wavefront per SIMD and are bound by instruction count; -O3's extra transformations
+# add instructions (A/B on one box: headline fp32 quad kernel 5.165 -> 5.269 M solves/s, resident interior-point fp64
+# 372 k -> 382 k QP/s; nothing measured got slower)
+FLAGS="--offload-arch=gfx950 -O2 -std=c++17 -fPIC -I../../include -mllvm -pragma-unroll-threshold=1000000"
 mkdir -p build
 pids=()
 for part in 1 2 3; do
@@ -17,9 +20,7 @@ done
 hipcc $FLAGS -c alqp_ipm.hip -o build/alqp_ipm.o "$@" &
 pids+=($!)
 # register/LDS-resident interior-point kernel: one object per dtype
-# (fp64 at -O2: measured 382 k against 372 k QP/s at -O3 on one box - the kernel is instruction-count bound and -O3's extra
-#  transformations add instructions; fp32 is indifferent)
-hipcc ${FLAGS/-O3/-O2} -DALQP_G4_F64 -c alqp_ipm_g4.hip -o build/alqp_ipm_g4_f64.o "$@" &
+hipcc $FLAGS -DALQP_G4_F64 -c alqp_ipm_g4.hip -o build/alqp_ipm_g4_f64.o "$@" &
 pids+=($!)
 hipcc $FLAGS -DALQP_G4_F32 -c alqp_ipm_g4.hip -o build/alqp_ipm_g4_f32.o "$@" &
 pids+=($!)

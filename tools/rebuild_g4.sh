@@ -3,8 +3,8 @@
 # (the other objects must exist from a full csrc/build.sh run). Extra arguments go to both hipcc compiles.
 set -euo pipefail
 cd "$(dirname "$0")/../deq-mpc-corl_amd/csrc"
-FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -I../../include -mllvm -pragma-unroll-threshold=1000000"
-hipcc ${FLAGS/-O3/-O2} -DALQP_G4_F64 -c alqp_ipm_g4.hip -o build/alqp_ipm_g4_f64.o "$@" &   # -O2: see csrc/build.sh
+FLAGS="--offload-arch=gfx950 -O2 -std=c++17 -fPIC -I../../include -mllvm -pragma-unroll-threshold=1000000"
+hipcc $FLAGS -DALQP_G4_F64 -c alqp_ipm_g4.hip -o build/alqp_ipm_g4_f64.o "$@" &
 p1=$!
 hipcc $FLAGS -DALQP_G4_F32 -c alqp_ipm_g4.hip -o build/alqp_ipm_g4_f32.o "$@" &
 p2=$!
