@@ -150,11 +150,37 @@ __device__ inline double team_bcast(double v, int src_in_team, int team_base) {
         return __shfl(v, team_base + src_in_team, 64);
     }
 }
+// A 32-bit move on the DPP network (row_shr:n = 0x110 + n, row_bcast15 = 0x142, row_bcast31 = 0x143); lanes whose source
+// is outside the row / not in `rows` read 0.
+template <int CTRL, int ROWS>
+__device__ inline float dpp_zfill(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROWS, 0xf, true));
+}
+template <int CTRL, int ROWS>
+__device__ inline double dpp_zfill(double v) {
+    const long long b = __builtin_bit_cast(long long, v);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(b & 0xffffffffll), CTRL, ROWS, 0xf, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, ROWS, 0xf, true);
+    return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
+}
 template <int G, typename real>
 __device__ inline real team_sum(real v) {
+    if constexpr (G == 64) {
+        // whole-wavefront team: scan inside the 16-lane rows, rows 0 / 2 into 1 / 3, the lower half into the upper - on the
+        // DPP network, no LDS round trip per step (the shuffle version: six exposed ds_bpermute round trips per sum, and the
+        // 20-candidate merit takes 23 sums per Newton step); lane 63 holds the total
+        v += dpp_zfill<0x111, 0xf>(v);
+        v += dpp_zfill<0x112, 0xf>(v);
+        v += dpp_zfill<0x114, 0xf>(v);
+        v += dpp_zfill<0x118, 0xf>(v);
+        v += dpp_zfill<0x142, 0xa>(v);
+        v += dpp_zfill<0x143, 0xc>(v);
+        return team_bcast<64>(v, 63, 0);
+    } else {
 #pragma unroll
-    for (int o = G / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+        for (int o = G / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+        return v;
+    }
 }
 template <int G>
 __device__ inline int team_or(int v) {
