@@ -570,10 +570,17 @@ struct Team {
                         if (isW || k < NX) frow[k] = Fs[base + k * stride];
                 }
                 // v = F_t' dx_{t+1}
+                // (Every mat-vec of this sweep reads ALL its LDS operands first and multiplies afterwards, the two
+                //  kept apart by a scheduling barrier: left to itself hipcc reuses two registers for the operands and
+                //  emits read, wait, two FMAs, seven times per product - 68 exposed LDS round trips per stage.)
                 if (isH) {
+                    real dv[NX];
+#pragma unroll
+                    for (int r = 0; r < NX; ++r) dv[r] = ds[(t + 1) * N + r];
+                    __builtin_amdgcn_sched_barrier(0);
                     real s = 0;
 #pragma unroll
-                    for (int r = 0; r < NX; ++r) s = fma_(frow[r], ds[(t + 1) * N + r], s);
+                    for (int r = 0; r < NX; ++r) s = fma_(frow[r], dv[r], s);
                     gs[hi] = s;
                 }
                 wave_sync();
@@ -582,10 +589,16 @@ struct Team {
             if (isH) {
                 real rhs = ds[t * N + hi];
                 if (dyn) {
+                    real xv[N], gv[N];
+#pragma unroll
+                    for (int i = 0; i < N; ++i) {
+                        xv[i] = Xt[(i * N - (i * (i - 1)) / 2) + (hi - i)];
+                        gv[i] = gs[i];
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
                     real s = 0;
 #pragma unroll
-                    for (int i = 0; i < N; ++i)
-                        s = fma_(keep_if_nonneg(Xt[(i * N - (i * (i - 1)) / 2) + (hi - i)], hi - i), gs[i], s);
+                    for (int i = 0; i < N; ++i) s = fma_(keep_if_nonneg(xv[i], hi - i), gv[i], s);
                     rhs = fma_(rho, s, rhs);
                 }
                 rs[hi] = rhs;
@@ -594,17 +607,26 @@ struct Team {
             // d_i = sum_{j>=i} X[i][j] rhs_j
             if (isH) {
                 const real *Xr = Xt + (hi * N - (hi * (hi - 1)) / 2) - hi;
+                real xv[N], rv[N];
+#pragma unroll
+                for (int j = 0; j < N; ++j) { xv[j] = Xr[j]; rv[j] = rs[j]; }
+                __builtin_amdgcn_sched_barrier(0);
                 real s = 0;
 #pragma unroll
-                for (int j = 0; j < N; ++j) s = fma_(keep_if_nonneg(Xr[j], j - hi), rs[j], s);
+                for (int j = 0; j < N; ++j) s = fma_(keep_if_nonneg(xv[j], j - hi), rv[j], s);
                 ds[t * N + hi] = s;
             }
             wave_sync();
             if (dyn && isW) {
+                real dv[N];
+#pragma unroll
+                for (int k = 0; k < N; ++k) dv[k] = ds[t * N + k];
+                const real dn = ds[(t + 1) * N + wr];
+                __builtin_amdgcn_sched_barrier(0);
                 real s = 0;
 #pragma unroll
-                for (int k = 0; k < N; ++k) s = fma_(frow[k], ds[t * N + k], s);
-                seq[t * NX + wr] = ds[(t + 1) * N + wr] - s;
+                for (int k = 0; k < N; ++k) s = fma_(frow[k], dv[k], s);
+                seq[t * NX + wr] = dn - s;
             }
         }
         if (li < NX) seq[(T - 1) * NX + li] = ds[li];
