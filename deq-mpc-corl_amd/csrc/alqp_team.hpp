@@ -313,8 +313,12 @@ struct Team {
                 wave_sync();
                 if (isW) {
                     real s = gc[t * NX + wr];
+                    real fv[N], zv[N];   // operands first, products after (see backward_sweep)
 #pragma unroll
-                    for (int k = 0; k < N; ++k) s = fma_(Fs[wr * N + k], zs[t * N + k], s);
+                    for (int k = 0; k < N; ++k) { fv[k] = Fs[wr * N + k]; zv[k] = zs[t * N + k]; }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int k = 0; k < N; ++k) s = fma_(fv[k], zv[k], s);
                     xn = s;
                 }
             }
@@ -644,27 +648,39 @@ struct Team {
                 // e = X_{t-1} y_{t-1}
                 if (isH) {
                     const real *Xr = Xq + (hi * N - (hi * (hi - 1)) / 2) - hi;
+                    real xv[N], dv[N];   // operands first, products after (see backward_sweep)
+#pragma unroll
+                    for (int j = 0; j < N; ++j) { xv[j] = Xr[j]; dv[j] = ds[(t - 1) * N + j]; }
+                    __builtin_amdgcn_sched_barrier(0);
                     real s = 0;
 #pragma unroll
-                    for (int j = 0; j < N; ++j) s = fma_(keep_if_nonneg(Xr[j], j - hi), ds[(t - 1) * N + j], s);
+                    for (int j = 0; j < N; ++j) s = fma_(keep_if_nonneg(xv[j], j - hi), dv[j], s);
                     gs[hi] = s;
                 }
                 wave_sync();
                 if (isW) {
+                    real fv[N], gv[N];
+#pragma unroll
+                    for (int k = 0; k < N; ++k) { fv[k] = Fs[wr * N + k]; gv[k] = gs[k]; }
+                    const real d0 = ds[t * N + wr];
+                    __builtin_amdgcn_sched_barrier(0);
                     real s = 0;
 #pragma unroll
-                    for (int k = 0; k < N; ++k) s = fma_(Fs[wr * N + k], gs[k], s);
-                    ds[t * N + wr] = fma_(rho, s, ds[t * N + wr]);
+                    for (int k = 0; k < N; ++k) s = fma_(fv[k], gv[k], s);
+                    ds[t * N + wr] = fma_(rho, s, d0);
                 }
                 wave_sync();
             }
             if (isH) rs[hi] = ds[t * N + hi];
             wave_sync();
             if (isH) {
+                real xv[N], rv[N];
+#pragma unroll
+                for (int i = 0; i < N; ++i) { xv[i] = Xt[(i * N - (i * (i - 1)) / 2) + (hi - i)]; rv[i] = rs[i]; }
+                __builtin_amdgcn_sched_barrier(0);
                 real s = 0;
 #pragma unroll
-                for (int i = 0; i < N; ++i)
-                    s = fma_(keep_if_nonneg(Xt[(i * N - (i * (i - 1)) / 2) + (hi - i)], hi - i), rs[i], s);
+                for (int i = 0; i < N; ++i) s = fma_(keep_if_nonneg(xv[i], hi - i), rv[i], s);
                 ds[t * N + hi] = s;
             }
             wave_sync();
