@@ -519,8 +519,15 @@ struct Team {
                 // identity entry: 1 on lane (identity row j), 0 elsewhere, as arithmetic on a
                 // per-lane float (a compare per j would be hoisted into 2 SGPRs each)
                 real acc = l[j] + fmax_(real(0), real(1) - fabs_(ufl - real(j)));
+                // row j of L first (j lane reads into j different scalar registers), the products after: hipcc otherwise
+                // reuses ONE scalar register and emits v_readlane, s_nop 1 (the scalar-write -> vector-read hazard), v_fma
+                // per term - twice the cycles of the 136 terms of a stage
+                real lj[N > 1 ? N - 1 : 1];
 #pragma unroll
-                for (int k = 0; k < j; ++k) acc = fma_(-l[k], team_bcast<G>(l[k], j, team_base), acc);
+                for (int k = 0; k < j; ++k) lj[k] = team_bcast<G>(l[k], j, team_base);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int k = 0; k < j; ++k) acc = fma_(-l[k], lj[k], acc);
                 real p = team_bcast<G>(acc, j, team_base);
                 if (!(p > 0) && info == 0) info = t * N + j + 1;
                 // no masking needed: H rows above the diagonal hold unused garbage, identity
