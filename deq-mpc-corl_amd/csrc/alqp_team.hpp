@@ -304,13 +304,16 @@ struct Team {
 
     // equality residual of every stage at the current zs -> req (kernel start)
     __device__ void residual_sweep() {
+        real fbuf[FCH];
+        if (!gxnext && T > 1) fetch_F(0, fbuf);
         for (int t = 0; t < T - 1; ++t) {
             real xn = 0;
             if (gxnext) {
                 if (isW) xn = gxnext[t * NX + wr];
             } else {
-                load_F(t);
-                wave_sync();
+                stash_F(fbuf);                               // F_t, fetched a stage ahead (its global round trip
+                wave_sync();                                 // runs under the previous stage's products)
+                if (t + 2 < T) fetch_F(t + 1, fbuf);
                 if (isW) {
                     real s = gc[t * NX + wr];
                     real fv[N], zv[N];   // operands first, products after (see backward_sweep)
