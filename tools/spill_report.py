@@ -9,7 +9,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "deq-mpc-corl_amd", "csrc")
 part = sys.argv[1] if len(sys.argv) > 1 else "1"
 out = os.path.join(tempfile.gettempdir(), f"alqp_part{part}.s")
-cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-I" + os.path.join(ROOT, "include"), "-mllvm",
+cmd = ["hipcc", "--offload-arch=gfx950", "-O2", "-std=c++17", "-I" + os.path.join(ROOT, "include"), "-mllvm",
        "-pragma-unroll-threshold=1000000", f"-DALQP_PART={part}", "-S", "--cuda-device-only",
        os.path.join(CSRC, "alqp_kernels.hip"), "-o", out] + sys.argv[2:]
 subprocess.run(cmd, check=True, stderr=subprocess.DEVNULL)
