@@ -894,6 +894,38 @@ struct Quad {
                 // and the step stays a descent direction for the line search to judge; the reference's
                 // half-finished cholesky_ex factor (al_utils.py:510-515) has nothing to restate
                 const real ip = rcp_(fabs_(p));
+                if constexpr (C::W_LDS) {
+                    // W lives in LDS (fp64): its columns are read KB at a time, ALL reads of a group first, then the
+                    // updates, then the writes. Element by element (read, 2-3 instructions, use, write - what hipcc makes
+                    // of the plain loop below) every one of the 544 read-modify-writes of a stage exposes most of an LDS
+                    // round trip to the one wavefront of the SIMD.
+                    constexpr int KB = 4;
+                    real wj[SW];
+#pragma unroll
+                    for (int s = 0; s < SW; ++s) wj[s] = W[s][j];
+#pragma unroll
+                    for (int k0 = j + 1; k0 < N; k0 += KB) {
+                        real wv[KB][SW];
+#pragma unroll
+                        for (int kk = 0; kk < KB; ++kk)
+#pragma unroll
+                            for (int s = 0; s < SW; ++s)
+                                if (k0 + kk < N) wv[kk][s] = W[s][k0 + kk];
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int kk = 0; kk < KB; ++kk) {
+                            const int k = k0 + kk;
+                            if (k < N) {
+                                const real lkj = qbv(H[C::hidx(k >> 2, j)], k) * ip;
+#pragma unroll
+                                for (int s = (k >> 2); s < SH; ++s) H[C::hidx(s, k)] = fma_(-H[C::hidx(s, j)], lkj, H[C::hidx(s, k)]);
+#pragma unroll
+                                for (int s = 0; s < SW; ++s) W[s][k] = fma_(-wj[s], lkj, wv[kk][s]);
+                                Y[k] = fma_(-Y[j], lkj, Y[k]);
+                            }
+                        }
+                    }
+                } else {
 #pragma unroll
                 for (int k = j + 1; k < N; ++k) {
                     const real lkj = qbv(H[C::hidx(k >> 2, j)], k) * ip;
@@ -902,6 +934,7 @@ struct Quad {
 #pragma unroll
                     for (int s = 0; s < SW; ++s) W[s][k] = fma_(-W[s][j], lkj, W[s][k]);
                     Y[k] = fma_(-Y[j], lkj, Y[k]);
+                }
                 }
                 if constexpr (C::S_AFTER) ipv[j] = ip;
                 if (!C::S_AFTER && dyn) {
