@@ -899,7 +899,7 @@ struct Quad {
                     // updates, then the writes. Element by element (read, 2-3 instructions, use, write - what hipcc makes
                     // of the plain loop below) every one of the 544 read-modify-writes of a stage exposes most of an LDS
                     // round trip to the one wavefront of the SIMD.
-                    constexpr int KB = 4;
+                    constexpr int KB = 8;
                     real wj[SW];
 #pragma unroll
                     for (int s = 0; s < SW; ++s) wj[s] = W[s][j];
