@@ -213,6 +213,27 @@ class MPC(Module):
         self.just_initialized = True
         self.warm_starting = True
 
+    @property
+    def last_status(self):
+        """Per-instance finiteness flag of the last solve (bool tensor), None before the first."""
+        raw = getattr(self, "_status_raw", None)
+        return None if raw is None else raw.bool()
+
+    @last_status.setter
+    def last_status(self, v):
+        self._status_raw = v
+
+    @property
+    def dyn_res_prev(self):
+        """||r+|| per instance after the last solve (AL_mpc.py's `dyn_res_prev`); the reference's initial 1000000 before."""
+        raw = getattr(self, "_rn2_raw", None)
+        return self._dyn_res_init if raw is None else raw.sqrt()
+
+    @dyn_res_prev.setter
+    def dyn_res_prev(self, v):
+        self._dyn_res_init = v
+        self._rn2_raw = None
+
     def get_xu(self):
         return torch.cat((self.x_init, self.u_init), dim=2)
 
@@ -398,7 +419,7 @@ class MPC(Module):
         st = _SolveState()
         st.mpc = self
         st.x0 = x0.detach().to(dt).contiguous()
-        st.z = torch.cat((x, u), dim=2).detach().to(dt).contiguous().clone()
+        st.z = torch.cat((x, u), dim=2).detach().to(dt).contiguous()   # (cat made a fresh tensor: no clone)
         st.lam = self.lamda_prev.detach().to(device=dev, dtype=dt).contiguous().clone()
         if self.state_estimator:   # [B, nx (T-1)] -> the kernels' layout; the init and bound rows stay 0
             st.lam = torch.cat((st.lam, st.lam.new_zeros(B, nrows - self.neq)), dim=1).contiguous()
@@ -561,8 +582,11 @@ class MPC(Module):
             if torch.is_tensor(getattr(st.dx, "F", None)) or self.linearize_once:
                 raise NotImplementedError("state_estimator: only the callable dx / dx_jac route exists "
                                           "(al_utils_se.py has no LinDx or frozen-linearisation branch)")
-        ws = {"phi": torch.zeros(B, dtype=dt, device=dev), "rn2": torch.zeros(B, dtype=dt, device=dev),
-              "info": torch.zeros(B, dtype=torch.int32, device=dev),
+        # phi, rn2 and info out of ONE zeroed allocation (one fill kernel instead of three)
+        esz = torch.empty((), dtype=dt).element_size()
+        zb = torch.zeros(B * (2 * esz + 4), dtype=torch.uint8, device=dev)
+        ws = {"phi": zb[:B * esz].view(dt), "rn2": zb[B * esz:2 * B * esz].view(dt),
+              "info": zb[2 * B * esz:].view(torch.int32),
               "status": torch.ones(B, dtype=torch.uint8, device=dev)}
         lin = st.lin
         if need_grad and self.linearize_once and st.stream_mode:
@@ -650,7 +674,7 @@ class MPC(Module):
                          factor=ws.get("factor"), al_iter=self.al_iter, max_newton=MAX_NEWTON,
                          n_ls=N_LS, flags=flags, rho_scale=RHO_SCALE, **extra)
             npa = [MAX_NEWTON] * self.al_iter
-            rho_last = st.rho / RHO_SCALE
+            rho_last = st.rho / RHO_SCALE if need_grad else None
             F_last = F
         elif (F is None and not stream and self.exit_mode == "fixed" and not has_obs
               and getattr(st.dx, "fused_id", None) is not None and hasattr(be, "solve_nonlin")
@@ -778,9 +802,11 @@ class MPC(Module):
                 raise RuntimeError("mi_alqp: a grid barrier of the in-kernel exit test timed out (ALQP_EXIT_IN_KERNEL); "
                                    "construct the MPC with exit_in_kernel=False")
         st.newton_per_al = npa
-        self.last_status = ws["status"].bool()
+        # (kept raw: `last_status` / `dyn_res_prev` are formed when read - two device kernels per call that a
+        #  solve whose caller never looks at them does not pay for; at the reference's batch size a call is ~0.6 ms)
+        self._status_raw = ws["status"]
         self.last_info = ws["info"]
-        self.dyn_res_prev = ws["rn2"].sqrt()
+        self._rn2_raw = ws["rn2"]
         if self.check_numerics is not None:
             n_piv = int((ws["info"] != 0).sum().item())
             n_bad = int((ws["status"] == 0).sum().item())
