@@ -121,9 +121,15 @@ class HipBackend:
             variant = self.default_variant
         vnum = {"auto": 0, "team": 1, "quad": 2}[variant]
         if vnum == 0:
-            # fp64 solve: the team kernels (uncapped build, round 2) hold on a little longer: 5.56 against 6.01 ms at
-            # B = 4096, 6.94 against 6.25 ms at B = 5120
-            qmin = self.QUAD_MIN_BATCH if dt != torch.float64 or self.QUAD_MIN_BATCH != 4096 else 4608
+            # the fused solve stays on the team kernels THROUGH B = 4096 (exactly two fp32 / four fp64 full rounds of
+            # teams; round 3: fp32 1.83 against 2.00 ms, fp64 4.35 against 4.71 ms there, quad ahead from B = 5120 on)
+            # (whole-wavefront teams only - 2n + nx + 1 > 32 rows, where it was measured; smaller teams keep round 2's rule)
+            if self.QUAD_MIN_BATCH != 4096:
+                qmin = self.QUAD_MIN_BATCH
+            elif 2 * (nx + nu) + nx + 1 > 32:
+                qmin = 4097
+            else:
+                qmin = 4608 if dt == torch.float64 else 4096
             vnum = 1 if ((flags & _lib.ALQP_SAVE_FACTOR) or B < qmin) else 2
             if vnum == 1 and not (flags & _lib.ALQP_SAVE_FACTOR) and not self.lib.alqp_supported_variant(C.byref(d), int(dt == torch.float64), 1):
                 vnum = 2   # horizon too long for the team's LDS image: the quad kernels run it at any batch

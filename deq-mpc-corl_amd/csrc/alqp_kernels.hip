@@ -1250,13 +1250,19 @@ int solve_lin_impl(const AlqpDims *dims, const AlqpParams *prm, const void *Qd, 
     const size_t need = quad_ws_bytes<real>(dims->nx, dims->nu, dims->B, dims->T);
     int variant = prm->variant;
     // auto: quad once the batch fills the chip (16 instances per wavefront, 1024 SIMDs), team below
-    // (2-2.4x lower latency at small batches; measured crossover at (13,4) T=20: B = 4096 in fp32, ~4600 in fp64)
+    // (2-2.4x lower latency at small batches). The team kernels' time is a step function of the batch - 2048 (fp32) /
+    // 1024 (fp64) teams fit the chip at once - and B = 4096 is exactly two / four full rounds: measured at (13,4) T=20
+    // after round 3's team-kernel work, fp32 B = 4096 team 1.83 vs quad 2.00 ms, B = 5120 2.36 vs 2.08; fp64 B = 4096 4.35
+    // vs 4.71, B = 5120 5.42 vs 5.02 (profiles/r03/experiments/README.md).
     if (variant == 0) {
         const size_t team_lds = lds_query<real>(dims->nx, dims->nu, dims->T);
         const bool team_fits = team_lds > 0 && team_lds <= kMaxLds;
         const bool quad_ok = need > 0 && workspace && ws_bytes >= need && !(prm->flags & ALQP_SAVE_FACTOR);
         // long horizons whose factor does not fit the team's LDS image run on the quad kernels at any batch
-        const int qmin = sizeof(real) == 8 ? 4608 : 4096;   // fp64: the uncapped team build wins up to ~4.5 k instances
+        // whole-wavefront teams (2n + nx + 1 > 32 rows, e.g. (13,4)): team through B = 4096 (full rounds), quad beyond;
+        // smaller teams share a wavefront and were not re-measured: round 2's rule
+        const bool wave_team = 2 * (dims->nx + dims->nu) + dims->nx + 1 > 32;
+        const int qmin = wave_team ? 4097 : (sizeof(real) == 8 ? 4608 : 4096);
         variant = (quad_ok && (dims->B >= qmin || !team_fits)) ? 2 : 1;
     }
     if (variant == 2) {
